@@ -1,0 +1,161 @@
+/*
+ * lmx.h — C-ABI of liblmx.so, the MI355X (gfx950) feature-extraction kernels that sit behind the
+ * yolo-pipeline / sam3-pipeline / dinov3-pipeline services of UBC-AWP/vision-sam3-yolo-lameless.
+ *
+ * The reference has no FFI of its own (it is pure Python: SURVEY.md §8b); the seam it offers is the three
+ * third-party call sites
+ *     services/yolo-pipeline/app/main.py:76      self.yolo_model(frame, verbose=False, conf=...)
+ *     services/sam3-pipeline/app/main.py:80-88   predictor.set_image(image); predictor.predict(box=...)
+ *     services/dinov3-pipeline/app/main.py:107-113  processor(images=...); model(**inputs).last_hidden_state.mean(1)
+ * Every entry point below replaces a piece of the arithmetic that runs under one of those calls; the comment
+ * on each one says which.  INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only enqueue work;
+ *   - return 0 on success, <0 on error; lmx_last_error() returns the thread-local message;
+ *   - activations are NHWC / token-major with the channel dimension contiguous, f16 unless said otherwise,
+ *     accumulation is always f32 (MFMA f32 accumulators), the ViT residual stream is f32;
+ *   - all "ld*" strides are in ELEMENTS of the tensor's dtype.
+ */
+#ifndef LMX_H
+#define LMX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMX_VERSION 100
+
+/* error codes */
+#define LMX_OK 0
+#define LMX_EINVAL (-1)  /* bad argument / unsupported shape (message says which) */
+#define LMX_EHIP (-2)    /* a HIP runtime call failed */
+
+typedef void* lmx_stream_t;
+
+int lmx_version(void);
+const char* lmx_last_error(void);
+/* number of visible HIP devices, <0 on error (used by the loader to fail loudly on a GPU-less box) */
+int lmx_device_count(void);
+
+/* ---- dtypes / activations -------------------------------------------------------------------------- */
+enum { LMX_F16 = 0, LMX_F32 = 1 };
+enum { LMX_ACT_NONE = 0, LMX_ACT_SILU = 1, LMX_ACT_GELU = 2 /* erf form */, LMX_ACT_RELU = 3 };
+
+/* ---- K3/K12/K2: GEMM / 1x1 conv / 3x3 conv (implicit GEMM), f16 in, f32 MFMA accumulate ------------
+ * C[m][n] = res[m][n] + scale[n] * act( sum_k A[m][k] * W[n][k] + bias[n] )
+ * Replaces: torch Linear / Conv2d(+folded BN)+SiLU under ultralytics' C2f/Conv/Detect (yolo main.py:76),
+ * the ViT qkv/proj/fc1/fc2 Linears under segment_anything's ImageEncoderViT (sam3 main.py:80) and under
+ * transformers' Dinov2/DINOv3 layers (dinov3 main.py:110-111).
+ *   a_mode 0: A is a row-major [M][K] f16 matrix with row stride lda.
+ *   a_mode 1: A is generated on the fly from an NHWC f16 image batch X[n][H][W][*] (pixel stride lda,
+ *             Cin channels used): kernel 3x3, pad 1, stride conv_stride; M = n*Ho*Wo, K = 9*Cin,
+ *             k = (ky*3+kx)*Cin + ci  (weights must be packed in that order).
+ * W is f16 [N][K] (K contiguous).  Requirements: K%8==0, N%4==0, lda%8==0, Cin%8==0, 16-byte aligned bases.
+ */
+typedef struct {
+  const void* A;
+  const void* W;
+  const float* bias;   /* [N] or NULL */
+  const float* scale;  /* [N] or NULL (LayerScale) */
+  const void* res;     /* [M][N] residual of dtype out_dtype, row stride ldr, or NULL; may alias C */
+  void* C;
+  int64_t lda, ldc, ldr;
+  int32_t M, N, K;
+  int32_t act;
+  int32_t out_dtype;   /* LMX_F16 / LMX_F32 */
+  int32_t a_mode;
+  /* a_mode 1 only */
+  int32_t H, W_, Cin, conv_stride, Ho, Wo;
+} lmx_gemm_desc;
+int lmx_k_gemm(const lmx_gemm_desc* d, lmx_stream_t stream);
+
+/* ---- K11: LayerNorm over the last dim, f32 or f16 in -> f16 or f32 out ------------------------------
+ * Replaces torch.nn.LayerNorm inside the ViT blocks (TF:models/dinov3_vit/modeling_dinov3_vit.py:400-445,
+ * TF:models/sam/modeling_sam.py:891-972).  One 64-lane wave per row, wave-shuffle reductions, two-pass
+ * variance (mean first) in f32.  D%4==0, D<=4096.
+ */
+int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const float* gamma, const float* beta,
+                    void* y, int out_dtype, int64_t ldy, int rows, int D, float eps, lmx_stream_t stream);
+
+/* ---- K13/K14: attention (flash-style, online softmax in f32, S and PV on MFMA) ----------------------
+ * O[b,t,h,:] = softmax_j( scale * Q[b,t,h,:] . K[b,j,h,:] ) V[b,j,h,:]
+ * Q/K/V/O are f16 with the head dim contiguous; element (row r, head h, d) sits at base + r*ld + h*hd + d
+ * where r is the token row.  geometry:
+ *   mode 0 (flat):    row = b*T + t                     (Tq queries, Tk keys per batch element)
+ *   mode 1 (window):  K/V tokens live on a [Gh][Gw] grid per image, partitioned into ws x ws windows
+ *                     (grid zero-padded up to a multiple of ws, as ImageEncoderViT.window_partition does);
+ *                     b = (img, wy, wx); key t -> (wy*ws + t/ws, wx*ws + t%ws).  Keys that fall in the
+ *                     padding take K = pad_k[h], V = pad_v[h] (= the qkv bias: what Linear(0) yields).
+ *                     Queries use the same map on a grid subsampled by q_stride (1, or 2 for Hiera Q-pool):
+ *                     grid [Gh/q][Gw/q]... see DESIGN.md §attention.
+ * hd%8==0, hd<=64.
+ */
+typedef struct {
+  const void* Q; const void* K; const void* V; void* O;
+  int64_t ldq, ldk, ldv, ldo;   /* token-row strides (elements) */
+  int32_t B, H, Tq, Tk, hd;
+  float scale;
+  int32_t mode;
+  /* mode 1 */
+  int32_t Gh, Gw, ws, q_stride;
+  const void* pad_k; const void* pad_v; /* f16 [H*hd] or NULL (zeros) */
+} lmx_attn_desc;
+int lmx_k_attention(const lmx_attn_desc* d, lmx_stream_t stream);
+
+/* ---- DINOv3 RoPE on the patch tokens of Q and K, in place (TF dinov3_vit :238-268) ------------------
+ * x[b, t, h, :] for t >= n_prefix is rotated: x' = x*cos + rotate_half(x)*sin with cos/sin f32 [T-n_prefix][hd].
+ */
+int lmx_k_rope(void* x, int64_t ld, int B, int T, int H, int hd, int n_prefix, const float* cos_t,
+               const float* sin_t, lmx_stream_t stream);
+
+/* ---- K9/K21: Pillow-exact separable u8 resize (two passes, 8bpc fixed-point coefficients) -----------
+ * Reproduces PIL.Image.resize(..., BICUBIC|BILINEAR, reducing_gap=None) on RGB u8 — the resampler behind
+ * AutoImageProcessor (dinov3 main.py:107) and SamPredictor.set_image -> ResizeLongestSide (sam3 main.py:80).
+ * Coefficient tables are computed on the host by the caller (lmx/resample.py restates Pillow's
+ * precompute_coeffs / normalize_coeffs_8bpc): bounds[2*out] = (xmin, xsize), kk[out*ksize] int32.
+ * Pass H: src [n][sh][sw][3] u8 -> tmp [n][sh][dw][3] u8 ; pass V: tmp -> dst [n][dh][dw][3] u8.
+ * swap_rb swaps channel 0 and 2 while reading src (cv2 BGR frame -> RGB, dinov3 main.py:98-99).
+ */
+int lmx_k_pil_resize_h(const uint8_t* src, uint8_t* dst, int n, int sh, int sw, int dw, const int32_t* bounds,
+                       const int32_t* kk, int ksize, int swap_rb, lmx_stream_t stream);
+int lmx_k_pil_resize_v(const uint8_t* src, uint8_t* dst, int n, int sh, int dh, int w, const int32_t* bounds,
+                       const int32_t* kk, int ksize, lmx_stream_t stream);
+
+/* crop + /255 + (x-mean)/std + write the ViT patch matrix directly (im2col of the k=P,s=P patch conv):
+ * out[(n*gh + py)*gw + px][(ky*P + kx)*3 + c] f16 (row stride ldo >= P*P*3; columns beyond P*P*3 are not
+ * written — the caller zeroes them once when ldo pads K to a multiple of 8), from u8 img [n][ih][iw][3] cropped
+ * at (top,left) to gh*P x gw*P.  (BitImageProcessor center_crop/rescale/normalize + Dinov*PatchEmbeddings' conv as a GEMM.)
+ * lut: DEVICE f32 [3][256], lut[c][u] = normalised value of byte u in channel c (built on the host with the
+ * processor's own expression, so rescale+normalize is exact by construction). */
+int lmx_k_patchify_norm(const uint8_t* img, void* out, int n, int ih, int iw, int top, int left, int gh, int gw,
+                        int P, int64_t ldo, const float* lut, lmx_stream_t stream);
+
+/* tokens: out[b][0..n_prefix) = prefix[t][:] (+pos), out[b][n_prefix + p] = patch[b*np + p][:] + pos[n_prefix+p]
+ * (f32 residual stream; pos may be NULL — DINOv3 has no learned position table). */
+int lmx_k_assemble_tokens(const void* patch_f16, const float* prefix, const float* pos, float* out, int B, int np,
+                          int n_prefix, int D, lmx_stream_t stream);
+
+/* K22: mean over all T tokens of a f16/f32 [B][T][D] tensor -> f32 [B][D]  (dinov3 main.py:113) */
+int lmx_k_token_mean(const void* x, int in_dtype, float* out, int B, int T, int D, lmx_stream_t stream);
+
+/* ---- K8: NMS (ultralytics non_max_suppression as invoked at yolo main.py:76) ------------------------
+ * pred f32 [n][A][4+nc] rows = (cx,cy,w,h, cls scores...) in letterboxed pixels.
+ * Per image: keep candidates with max class score > conf; best class; sort by score descending (ties: lower
+ * anchor index first); boxes offset by cls*max_wh; greedy IoU > iou suppression (torchvision.ops.nms
+ * semantics, IoU computed exactly as torchvision's CPU kernel: f32, no FMA contraction, compared against the
+ * DOUBLE threshold as `ovr > iou_threshold` does there); first max_det.  A <= 16384.
+ * Outputs (row-major, caller allocated): boxes f32 [n][max_det][4] xyxy in letterboxed pixels (before
+ * scale_boxes), scores f32 [n][max_det], cls int32 [n][max_det], src int32 [n][max_det] (anchor index),
+ * counts int32 [n].  workspace: lmx_nms_workspace_bytes(n, A) bytes.
+ */
+int64_t lmx_nms_workspace_bytes(int n, int A);
+int lmx_k_nms(const float* pred, int n, int A, int nc, float conf, double iou, int max_det, float max_wh,
+              float* boxes, float* scores, int32_t* cls, int32_t* src, int32_t* counts, void* workspace,
+              lmx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

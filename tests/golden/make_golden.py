@@ -1,0 +1,72 @@
+"""Regenerates the committed golden vectors.  Run in the build container (CPU):  python tests/golden/make_golden.py
+
+The reference holds no vectors for this path and its services cannot be imported here (cv2 /
+ultralytics / nats missing, §8c), so the vectors come from the third-party model code the services call, as installed
+in the container: transformers' DINOv3ViTModel / Dinov2Model (eager attention, fp32, CPU) fed by the PIL image
+processor — with the build's deterministic synthetic weights (lmx.weights, seed in the file name) because no
+checkpoint exists offline.  Only inputs' seeds and outputs are stored (no weights, no third-party source)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vision-sam3-yolo-lameless_amd")]
+
+from lmx import dino, synth, weights  # noqa: E402
+from oracle import preprocess as OP  # noqa: E402
+from oracle import vit  # noqa: E402
+
+
+def hf_dino(cfg, sd):
+    if cfg.arch == "dinov3":
+        from transformers import DINOv3ViTConfig, DINOv3ViTModel
+
+        c = DINOv3ViTConfig(hidden_size=cfg.hidden, intermediate_size=cfg.mlp, num_hidden_layers=cfg.layers,
+                            num_attention_heads=cfg.heads, num_register_tokens=cfg.registers, patch_size=cfg.patch,
+                            layer_norm_eps=cfg.eps, rope_theta=cfg.rope_theta, image_size=cfg.image,
+                            attn_implementation="eager")
+        m = DINOv3ViTModel(c)
+    else:
+        from transformers import Dinov2Config, Dinov2Model
+
+        c = Dinov2Config(hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                         mlp_ratio=cfg.mlp // cfg.hidden, patch_size=cfg.patch, image_size=cfg.pos_grid * cfg.patch,
+                         layer_norm_eps=cfg.eps, attn_implementation="eager")
+        m = Dinov2Model(c)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.eval()
+
+
+def hf_pixel_values(frames_bgr):
+    from PIL import Image
+    from transformers.models.bit.image_processing_pil_bit import BitImageProcessorPil
+
+    proc = BitImageProcessorPil(size={"shortest_edge": 256}, crop_size={"height": 224, "width": 224},
+                                image_mean=list(OP.IMAGENET_MEAN), image_std=list(OP.IMAGENET_STD), resample=3)
+    return torch.cat([proc(images=Image.fromarray(np.ascontiguousarray(f[:, :, ::-1])), return_tensors="pt")["pixel_values"]
+                      for f in frames_bgr], 0)
+
+
+def make_dino(name, cfg, seed, frame_ids, clip_seed):
+    sd = weights.synth_state_dict(dino.param_spec(cfg), seed)
+    frames = np.stack([synth.synth_frame(clip_seed, i) for i in frame_ids], 0)
+    pv = hf_pixel_values(frames)
+    with torch.no_grad():
+        hs = hf_dino(cfg, sd)(pixel_values=pv).last_hidden_state
+        emb = hs.mean(dim=1)  # services/dinov3-pipeline/app/main.py:113
+        ours = vit.embed(cfg, sd, pv)
+    cos = torch.nn.functional.cosine_similarity(emb, ours, dim=1)
+    print(name, "oracle-vs-transformers max abs", float((emb - ours).abs().max()), "min cos", float(cos.min()))
+    assert float((emb - ours).abs().max()) < 5e-4
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), embedding=emb.numpy(), cls_token=hs[:, 0].numpy(),
+                        weight_seed=seed, clip_seed=clip_seed, frame_ids=np.asarray(frame_ids),
+                        pixel_checksum=np.asarray([int(pv.double().abs().sum() * 1000)]))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    make_dino("dinov3_vitl16_w3", dino.dinov3_vitl16(), 3, [0, 75, 149], clip_seed=4)
+    make_dino("dinov2_base_w4", dino.dinov2_base(), 4, [0, 30], clip_seed=5)

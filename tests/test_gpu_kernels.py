@@ -1,0 +1,293 @@
+"""Per-kernel parity of liblmx (through the C-ABI) against plain fp32 CPU references on the same seeded inputs.
+Tolerances: integer/byte/index kernels bit-exact; f16-output kernels within f16 rounding of the fp32 result."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def _close(got, ref, atol, rtol, what):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol)
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} at ref {float(ref.flatten()[err.argmax()]):.4g}"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (201, 1024, 1024), (77, 80, 72), (1000, 336, 112), (513, 64, 2048),
+                                   (4096, 3072, 1024)])
+@pytest.mark.parametrize("out_dtype", [torch.float16, torch.float32])
+def test_gemm_plain(cuda, M, N, K, out_dtype):
+    from lmx import kernels as Kk
+
+    a = _rand((M, K), 1).half()
+    w = _rand((N, K), 2, K ** -0.5).half()
+    b = _rand((N,), 3)
+    ref = a.float() @ w.float().t() + b
+    got = Kk.gemm(a.to(cuda), w.to(cuda), bias=b.to(cuda), out_dtype=out_dtype)
+    tol = dict(atol=2e-3, rtol=2e-3) if out_dtype == torch.float16 else dict(atol=2e-4, rtol=1e-4)
+    _close(got, ref, what=f"gemm {M}x{N}x{K}", **tol)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_epilogues(cuda, act):
+    from lmx import kernels as Kk
+
+    M, N, K = 300, 256, 192
+    a = _rand((M, K), 4).half()
+    w = _rand((N, K), 5, K ** -0.5).half()
+    b, s = _rand((N,), 6), _rand((N,), 7)
+    res = _rand((M, N), 8)
+    y = a.float() @ w.float().t() + b
+    y = [y, F.silu(y), F.gelu(y), F.relu(y)][act]
+    ref = y * s + res
+    # f32 residual stream updated in place through a strided view (ld > N)
+    buf = torch.zeros((M, N + 64), dtype=torch.float32)
+    buf[:, :N] = res
+    buf = buf.to(cuda)
+    view = buf[:, :N]
+    Kk.gemm(a.to(cuda), w.to(cuda), bias=b.to(cuda), act=act, scale=s.to(cuda), res=view, out=view)
+    _close(view, ref, 3e-4, 1e-4, f"gemm epilogue act={act}")
+    assert float(buf[:, N:].abs().max()) == 0.0
+    # f16 in/out with f16 residual
+    resh = res.half()
+    ref16 = y * s + resh.float()
+    got = Kk.gemm(a.to(cuda), w.to(cuda), bias=b.to(cuda), act=act, scale=s.to(cuda), res=resh.to(cuda),
+                  out_dtype=torch.float16)
+    _close(got, ref16, 4e-3, 2e-3, f"gemm f16 epilogue act={act}")
+
+
+@pytest.mark.parametrize("n,H,W,Cin,Cout,stride", [(2, 20, 20, 64, 128, 1), (1, 33, 47, 16, 24, 2), (2, 40, 24, 128, 64, 2),
+                                                    (1, 80, 80, 256, 256, 1)])
+def test_conv3x3(cuda, n, H, W, Cin, Cout, stride):
+    from lmx import kernels as Kk
+
+    x = _rand((n, H, W, Cin), 10).half()
+    w = _rand((Cout, Cin, 3, 3), 11, (9 * Cin) ** -0.5).half()
+    b = _rand((Cout,), 12, 0.1)
+    ref = F.silu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, stride=stride, padding=1)).permute(0, 2, 3, 1)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    got = Kk.conv3x3(x.to(cuda), wp.to(cuda), bias=b.to(cuda), act=Kk.ACT_SILU, stride=stride)
+    _close(got, ref, 3e-3, 3e-3, f"conv3x3 {n}x{H}x{W}x{Cin}->{Cout} s{stride}")
+
+
+def test_conv_channel_slices_and_residual(cuda):
+    """C2f plumbing: read a channel slice, write another slice of the same buffer, add the shortcut."""
+    from lmx import kernels as Kk
+
+    n, H, W, C = 2, 16, 12, 32
+    buf = _rand((n, H, W, 4 * C), 13).half()
+    w = _rand((C, C, 3, 3), 14, (9 * C) ** -0.5).half()
+    b = _rand((C,), 15, 0.1)
+    xin = buf[..., C:2 * C]
+    ref = buf.clone().float()
+    y = F.silu(F.conv2d(xin.float().permute(0, 3, 1, 2), w.float(), b, padding=1)).permute(0, 2, 3, 1)
+    ref[..., 2 * C:3 * C] = y + xin.float()
+    d = buf.to(cuda)
+    wp = w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous().to(cuda)
+    Kk.conv3x3(d[..., C:2 * C], wp, bias=b.to(cuda), res=d[..., C:2 * C], out=d[..., 2 * C:3 * C])
+    _close(d, ref, 4e-3, 3e-3, "conv slice/residual")
+    # 1x1 over the whole concat buffer into a fresh tensor
+    w1 = _rand((48, 4 * C), 16, (4 * C) ** -0.5).half()
+    ref1 = F.silu(ref.half().float() @ w1.float().t())
+    got1 = Kk.conv1x1(d, w1.to(cuda), act=Kk.ACT_SILU)
+    _close(got1, ref1, 5e-3, 5e-3, "conv1x1")
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,D", [(5, 112), (201, 1024), (64, 1280), (3, 4096)])
+def test_layernorm(cuda, rows, D):
+    from lmx import kernels as Kk
+
+    x = _rand((rows, D), 20, 3.0) + 0.5
+    g, b = _rand((D,), 21) * 0.1 + 1, _rand((D,), 22) * 0.1
+    ref = F.layer_norm(x, (D,), g, b, 1e-5)
+    got = Kk.layernorm(x.to(cuda), g.to(cuda), b.to(cuda), 1e-5, out_dtype=torch.float32)
+    _close(got, ref, 2e-5, 2e-5, "layernorm f32")
+    got16 = Kk.layernorm(x.to(cuda), g.to(cuda), b.to(cuda), 1e-5)
+    _close(got16, ref, 2e-3, 1e-3, "layernorm f16 out")
+    got_h = Kk.layernorm(x.half().to(cuda), g.to(cuda), b.to(cuda), 1e-5, out_dtype=torch.float32)
+    _close(got_h, F.layer_norm(x.half().float(), (D,), g, b, 1e-5), 2e-5, 2e-5, "layernorm f16 in")
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale):
+    w = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
+    return w @ v
+
+
+@pytest.mark.parametrize("B,H,T,hd", [(2, 16, 201, 64), (3, 2, 64, 56), (1, 4, 300, 32), (2, 3, 16, 64), (1, 2, 1000, 56)])
+def test_attention_flat(cuda, B, H, T, hd):
+    from lmx import kernels as Kk
+
+    D = H * hd
+    qkv = _rand((B * T, 3 * D), 30, 1.5).half()
+    q, k, v = (qkv[:, i * D:(i + 1) * D].float().view(B, T, H, hd).transpose(1, 2) for i in range(3))
+    ref = _attn_ref(q, k, v, hd ** -0.5).transpose(1, 2).reshape(B * T, D)
+    d = qkv.to(cuda)
+    out = torch.zeros((B * T, D), dtype=torch.float16, device=cuda)
+    Kk.attention(d[:, :D], d[:, D:2 * D], d[:, 2 * D:], out, B, H, T, T, hd, hd ** -0.5)
+    _close(out, ref, 3e-3, 3e-3, f"attention B{B} H{H} T{T} hd{hd}")
+
+
+def _window_ref(x_q, x_k, x_v, Gh, Gw, ws, heads, hd, pad_k, pad_v, q_stride=1):
+    """window_partition with zero padding replaced by the qkv-bias rows, attention per window, unpartition."""
+    n = x_k.shape[0] // (Gh * Gw)
+    D = heads * hd
+
+    def part(x, padrow, gh, gw, w):
+        x = x.view(n, gh, gw, D)
+        php, pwp = (-gh) % w, (-gw) % w
+        if php or pwp:
+            full = padrow.view(1, 1, 1, D).expand(n, gh + php, gw + pwp, D).clone()
+            full[:, :gh, :gw] = x
+            x = full
+        Hp, Wp = x.shape[1], x.shape[2]
+        x = x.view(n, Hp // w, w, Wp // w, w, D).permute(0, 1, 3, 2, 4, 5).reshape(-1, w * w, D)
+        return x, (Hp, Wp)
+
+    kx, _ = part(x_k, pad_k, Gh, Gw, ws)
+    vx, _ = part(x_v, pad_v, Gh, Gw, ws)
+    wq = ws // q_stride
+    qx, (Hq, Wq) = part(x_q, torch.zeros(D), Gh // q_stride, Gw // q_stride, wq)
+    nb = kx.shape[0]
+    qh = qx.view(nb, wq * wq, heads, hd).transpose(1, 2)
+    kh = kx.view(nb, ws * ws, heads, hd).transpose(1, 2)
+    vh = vx.view(nb, ws * ws, heads, hd).transpose(1, 2)
+    o = _attn_ref(qh, kh, vh, hd ** -0.5).transpose(1, 2).reshape(nb, wq * wq, D)
+    o = o.view(n, Hq // wq, Wq // wq, wq, wq, D).permute(0, 1, 3, 2, 4, 5).reshape(n, Hq, Wq, D)
+    return o[:, :Gh // q_stride, :Gw // q_stride].reshape(-1, D)
+
+
+@pytest.mark.parametrize("n,Gh,Gw,ws,heads,hd,qs", [(2, 16, 16, 8, 2, 56, 1), (1, 20, 20, 14, 4, 56, 1), (2, 12, 12, 4, 3, 64, 1),
+                                                    (1, 64, 64, 14, 2, 64, 1), (1, 16, 16, 8, 4, 56, 2), (1, 20, 20, 14, 2, 56, 2)])
+def test_attention_window(cuda, n, Gh, Gw, ws, heads, hd, qs):
+    from lmx import kernels as Kk
+
+    D = heads * hd
+    rows = n * Gh * Gw
+    qkv = _rand((rows, 3 * D), 31, 1.5).half()
+    bias = _rand((3 * D,), 32).half()
+    kf, vf = qkv[:, D:2 * D].float(), qkv[:, 2 * D:].float()
+    if qs == 1:
+        qd = qkv[:, :D].contiguous()
+    else:  # Hiera Q-pool: queries live on the 2x-subsampled grid
+        qd = _rand((n * (Gh // 2) * (Gw // 2), D), 33, 1.5).half()
+    ref = _window_ref(qd.float(), kf, vf, Gh, Gw, ws, heads, hd, bias[D:2 * D].float(), bias[2 * D:].float(), qs)
+    d = qkv.to(cuda)
+    bd = bias.to(cuda)
+    nW = -(-Gh // ws) * -(-Gw // ws)
+    out = torch.zeros((qd.shape[0], D), dtype=torch.float16, device=cuda)
+    wq = ws // qs
+    Kk.attention(qd.to(cuda), d[:, D:2 * D], d[:, 2 * D:], out, n * nW, heads, wq * wq, ws * ws, hd, hd ** -0.5,
+                 window=dict(Gh=Gh, Gw=Gw, ws=ws, q_stride=qs), pad_k=bd[D:2 * D], pad_v=bd[2 * D:])
+    _close(out, ref, 3e-3, 3e-3, f"window attention {Gh}x{Gw} ws{ws} qs{qs}")
+
+
+def test_rope(cuda):
+    from lmx import dino
+    from lmx import kernels as Kk
+    from oracle import vit
+
+    cfg = dino.DinoConfig(hidden=128, heads=2)
+    B, T, H, hd, npre = 2, 5 + 196, 2, 64, 5
+    x = _rand((B * T, 3 * H * hd), 40).half()
+    cos, sin = vit.rope_tables(hd, 100.0, 14, 14)
+    q = x[:, :H * hd].float().view(B, T, H, hd)
+    pat = q[:, npre:]
+    rot = torch.cat((-pat[..., hd // 2:], pat[..., :hd // 2]), -1)
+    ref = q.clone()
+    ref[:, npre:] = pat * cos[None, :, None, :] + rot * sin[None, :, None, :]
+    d = x.to(cuda)
+    Kk.rope(d[:, :H * hd], B, T, H, hd, npre, cos.to(cuda), sin.to(cuda))
+    _close(d[:, :H * hd], ref.reshape(B * T, H * hd), 2e-3, 2e-3, "rope")
+    assert torch.equal(d[:, H * hd:].cpu(), x[:, H * hd:])
+
+
+# --------------------------------------------------------------------------------------- preprocessing
+@pytest.mark.parametrize("h,w", [(1080, 1920), (720, 1280), (300, 256)])
+def test_dino_preprocess_bit_exact(cuda, h, w):
+    """u8 resize must equal Pillow bit for bit; the patch matrix must equal f16(pixel_values) exactly."""
+    from lmx import dino, weights
+    from oracle import preprocess as OP
+
+    cfg = dino.DinoConfig(hidden=64, layers=1, heads=1, mlp=64)
+    emb = dino.DinoEmbedder(cfg, weights.synth_state_dict(dino.param_spec(cfg), 1), cuda)
+    frames = np.random.default_rng(50).integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    # smooth one frame so the resampler is not fed pure noise only
+    frames[1] = (np.add.outer(np.arange(h), np.arange(w))[:, :, None] // 7 % 256).astype(np.uint8)
+    patches = emb.preprocess(torch.from_numpy(frames).to(cuda)).cpu()
+    for i in range(2):
+        pv = torch.from_numpy(OP.dino_pixel_values(frames[i]))  # [3,224,224]
+        ref = pv.view(3, 14, 16, 14, 16).permute(1, 3, 2, 4, 0).reshape(196, 768).half()
+        assert torch.equal(patches[i * 196:(i + 1) * 196], ref), f"frame {i} of {h}x{w}"
+
+
+def test_token_mean_and_assemble(cuda):
+    from lmx import kernels as Kk
+
+    B, np_, npre, D = 3, 10, 2, 64
+    patch = _rand((B * np_, D), 60).half()
+    prefix, pos = _rand((npre, D), 61), _rand((np_ + npre, D), 62)
+    ref = torch.cat([prefix.expand(B, -1, -1), patch.float().view(B, np_, D)], 1) + pos
+    got = Kk.assemble_tokens(patch.to(cuda), prefix.to(cuda), pos.to(cuda), B, np_, npre, D)
+    assert torch.equal(got.cpu().view(B, np_ + npre, D), ref)
+    m = Kk.token_mean(got, B, np_ + npre, D)
+    _close(m, ref.mean(1), 1e-6, 1e-6, "token_mean")
+
+
+# ------------------------------------------------------------------------------------------------- NMS
+def _run_nms(cuda, pred, conf, iou=0.7, max_det=300):
+    from lmx import kernels as Kk
+
+    b, s, c, src, cnt = Kk.nms(torch.from_numpy(pred).to(cuda), conf, iou, max_det)
+    torch.cuda.synchronize()
+    return b.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), src.cpu().numpy(), cnt.cpu().numpy()
+
+
+@pytest.mark.parametrize("A,nc,conf,seed", [(8400, 80, 0.25, 0), (8400, 80, 0.001, 1), (5040, 80, 0.5, 2), (300, 3, 0.1, 3),
+                                            (16384, 2, 0.05, 4)])
+def test_nms_bit_exact(cuda, A, nc, conf, seed):
+    from oracle import nms as ON
+
+    rng = np.random.default_rng(seed)
+    n = 3
+    pred = np.zeros((n, A, 4 + nc), np.float32)
+    # clustered boxes so that suppression chains actually occur
+    centers = rng.uniform(50, 590, (n, 40, 2))
+    which = rng.integers(0, 40, (n, A))
+    pred[..., 0:2] = np.take_along_axis(centers, which[..., None].repeat(2, -1), 1) + rng.normal(0, 6, (n, A, 2))
+    pred[..., 2:4] = rng.uniform(20, 120, (n, A, 2))
+    pred[..., 4:] = rng.uniform(0, 1, (n, A, nc)).astype(np.float32) ** 6
+    pred[0, :50, 4:] = pred[0, 50:100, 4:]  # exact score ties between different anchors
+    b, s, c, src, cnt = _run_nms(cuda, pred, conf)
+    for i in range(n):
+        rb, rs, rc, rsrc = ON.non_max_suppression(pred[i], conf)
+        k = len(rsrc)
+        assert cnt[i] == k, f"image {i}: count {cnt[i]} != {k}"
+        assert np.array_equal(src[i, :k], rsrc), f"image {i}: keep set differs"
+        assert np.array_equal(c[i, :k], rc)
+        assert np.array_equal(s[i, :k], rs)
+        assert np.array_equal(b[i, :k], rb)
+
+
+def test_nms_known_answers(cuda):
+    from test_nms_oracle import _pred
+
+    p = _pred([[0, 0, 100, 100], [0, 0, 100, 81], [0, 0, 100, 70], [200, 200, 300, 300]], [0.9, 0.8, 0.85, 0.7], [0, 0, 0, 0])
+    _, _, _, src, cnt = _run_nms(cuda, p[None], 0.25)
+    assert cnt[0] == 3 and src[0, :3].tolist() == [0, 2, 3]  # IoU 0.81 suppressed, IoU f32(0.7) kept
+    n = 400
+    p = _pred([[i * 20, 0, i * 20 + 10, 10] for i in range(n)], [0.75] * n, [0] * n)
+    _, _, _, src, cnt = _run_nms(cuda, p[None], 0.25)
+    assert cnt[0] == 300 and src[0].tolist() == list(range(300))
+    p = _pred([[0, 0, 10, 10]], [0.1], [0])
+    _, _, _, src, cnt = _run_nms(cuda, p[None], 0.25)
+    assert cnt[0] == 0

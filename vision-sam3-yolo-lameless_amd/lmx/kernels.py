@@ -1,0 +1,246 @@
+"""Thin torch-tensor front end of the C-ABI (include/lmx.h).  PyTorch is used for device memory and streams only:
+every function below checks shapes/strides on the host, fills the C descriptor and enqueues ONE liblmx kernel on
+torch's current HIP stream.  No arithmetic happens in Python and there is no fallback path."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, GemmDesc, LmxError, check
+
+F16, F32 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
+_DT = {torch.float16: F16, torch.float32: F32}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise LmxError("lmx kernels take device (HBM) tensors only; got a CPU tensor")
+
+
+def _rows(t, what):
+    """2-D row-major view: last dim contiguous; returns (rows, cols, row_stride)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise LmxError(f"{what}: expected a 2-D tensor with contiguous last dim, got shape {tuple(t.shape)} "
+                       f"strides {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtype=torch.float16):
+    """out[M,N] = res + scale * act(a[M,K] @ w[N,K]^T + bias)   (lmx_k_gemm, a_mode 0)."""
+    _dev(a, w, bias, scale, res, out)
+    M, K, lda = _rows(a, "gemm A")
+    N, K2, ldw = _rows(w, "gemm W")
+    if K2 != K or ldw != K:
+        raise LmxError(f"gemm: W must be contiguous [N,K]; A K={K}, W shape {tuple(w.shape)}")
+    if a.dtype != torch.float16 or w.dtype != torch.float16:
+        raise LmxError("gemm: A and W must be float16")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    Mo, No, ldc = _rows(out, "gemm C")
+    if (Mo, No) != (M, N):
+        raise LmxError(f"gemm: out shape {tuple(out.shape)} != ({M},{N})")
+    d = GemmDesc()
+    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.lda, d.ldc, d.ldr = lda, ldc, 0
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
+        raise LmxError("gemm: bias must be float32 [N]")
+    if scale is not None and (scale.dtype != torch.float32 or scale.numel() != N):
+        raise LmxError("gemm: scale must be float32 [N]")
+    if res is not None:
+        Mr, Nr, ldr = _rows(res, "gemm res")
+        if (Mr, Nr) != (M, N) or res.dtype != out.dtype:
+            raise LmxError("gemm: residual must match out's shape and dtype")
+        d.res, d.ldr = res.data_ptr(), ldr
+    d.M, d.N, d.K = M, N, K
+    d.act, d.out_dtype, d.a_mode = act, _DT[out.dtype], 0
+    check(_lib.load().lmx_k_gemm(C.byref(d), _stream()), "lmx_k_gemm")
+    return out
+
+
+def _nhwc(t, what):
+    """[n,H,W,C] view of (a channel slice of) a dense NHWC buffer; returns (n,H,W,C,pixel_stride)."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise LmxError(f"{what}: expected NHWC with contiguous channels, got {tuple(t.shape)} / {t.stride()}")
+    n, H, W, Cc = t.shape
+    ps = t.stride(2)
+    if t.stride(1) != W * ps or (n > 1 and t.stride(0) != H * W * ps):
+        raise LmxError(f"{what}: not a channel slice of a dense NHWC buffer: strides {t.stride()}")
+    return n, H, W, Cc, ps
+
+
+def conv3x3(x, w, bias=None, act=ACT_SILU, stride=1, res=None, out=None):
+    """3x3 / pad 1 convolution as implicit GEMM (lmx_k_gemm, a_mode 1).  x: NHWC f16 (may be a channel slice),
+    w: f16 [Cout, 9*Cin] packed (ky,kx,ci); out: NHWC f16 (may be a channel slice of a wider buffer)."""
+    _dev(x, w, bias, res, out)
+    n, H, W, Cin, ps = _nhwc(x, "conv3x3 x")
+    Cout = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != 9 * Cin or not w.is_contiguous():
+        raise LmxError(f"conv3x3: W must be contiguous [Cout, 9*Cin={9 * Cin}], got {tuple(w.shape)}")
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    if out is None:
+        out = torch.empty((n, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
+    no, Ho2, Wo2, Co2, pso = _nhwc(out, "conv3x3 out")
+    if (no, Ho2, Wo2, Co2) != (n, Ho, Wo, Cout):
+        raise LmxError(f"conv3x3: out shape {tuple(out.shape)} != {(n, Ho, Wo, Cout)}")
+    d = GemmDesc()
+    d.A, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.scale = None
+    d.lda, d.ldc, d.ldr = ps, pso, 0
+    if res is not None:
+        nr, Hr, Wr, Cr, psr = _nhwc(res, "conv3x3 res")
+        if (nr, Hr, Wr, Cr) != (n, Ho, Wo, Cout) or res.dtype != out.dtype:
+            raise LmxError("conv3x3: residual must match out")
+        d.res, d.ldr = res.data_ptr(), psr
+    d.M, d.N, d.K = n * Ho * Wo, Cout, 9 * Cin
+    d.act, d.out_dtype, d.a_mode = act, F16, 1
+    d.H, d.W_, d.Cin, d.conv_stride, d.Ho, d.Wo = H, W, Cin, stride, Ho, Wo
+    check(_lib.load().lmx_k_gemm(C.byref(d), _stream()), "lmx_k_gemm(conv3x3)")
+    return out
+
+
+def conv1x1(x, w, bias=None, act=ACT_SILU, res=None, out=None, out_dtype=torch.float16):
+    """1x1 convolution = GEMM over the pixels of an NHWC tensor (channel slices allowed on both sides)."""
+    n, H, W, Cin, ps = _nhwc(x, "conv1x1 x")
+    a = x.as_strided((n * H * W, Cin), (ps, 1))
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty((n, H, W, Cout), dtype=out_dtype, device=x.device)
+    no, Ho, Wo, Co, pso = _nhwc(out, "conv1x1 out")
+    o2 = out.as_strided((n * H * W, Cout), (pso, 1))
+    r2 = None
+    if res is not None:
+        nr, Hr, Wr, Cr, psr = _nhwc(res, "conv1x1 res")
+        r2 = res.as_strided((n * H * W, Cout), (psr, 1))
+    gemm(a, w, bias=bias, act=act, res=r2, out=o2)
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16):
+    _dev(x, gamma, beta, out)
+    rows, D, ldx = _rows(x, "layernorm x")
+    if out is None:
+        out = torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    r2, D2, ldy = _rows(out, "layernorm y")
+    if (r2, D2) != (rows, D):
+        raise LmxError("layernorm: out shape mismatch")
+    check(_lib.load().lmx_k_layernorm(_ptr(x), _DT[x.dtype], ldx, _ptr(gamma), _ptr(beta), _ptr(out), _DT[out.dtype],
+                                      ldy, rows, D, float(eps), _stream()), "lmx_k_layernorm")
+    return out
+
+
+def attention(q, k, v, out, B, H, Tq, Tk, hd, scale, window=None, pad_k=None, pad_v=None):
+    """q/k/v/out: 2-D token-row views [rows, >=H*hd] (row stride = ld).  window = None (flat: row = b*T + t) or
+    dict(Gh, Gw, ws, q_stride) for in-place window addressing on the token grid."""
+    _dev(q, k, v, out, pad_k, pad_v)
+    d = AttnDesc()
+    d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    for t in (q, k, v, out):
+        if t.dtype != torch.float16 or t.stride(-1) != 1:
+            raise LmxError("attention: q/k/v/out must be float16 with contiguous last dim")
+    d.B, d.H, d.Tq, d.Tk, d.hd = B, H, Tq, Tk, hd
+    d.scale = float(scale)
+    if window is None:
+        d.mode = 0
+    else:
+        d.mode = 1
+        d.Gh, d.Gw, d.ws, d.q_stride = window["Gh"], window["Gw"], window["ws"], window.get("q_stride", 1)
+        d.pad_k = pad_k.data_ptr() if pad_k is not None else None
+        d.pad_v = pad_v.data_ptr() if pad_v is not None else None
+    check(_lib.load().lmx_k_attention(C.byref(d), _stream()), "lmx_k_attention")
+    return out
+
+
+def rope(x, B, T, H, hd, n_prefix, cos_t, sin_t):
+    _dev(x, cos_t, sin_t)
+    check(_lib.load().lmx_k_rope(_ptr(x), x.stride(0), B, T, H, hd, n_prefix, _ptr(cos_t), _ptr(sin_t), _stream()),
+          "lmx_k_rope")
+    return x
+
+
+def pil_resize(src, dw, dh, tab_h, tab_v, swap_rb=False):
+    """Pillow-exact two-pass resize of u8 [n,sh,sw,3] -> [n,dh,dw,3].  tab_* = (bounds i32 [2*out], kk i32
+    [out*ksize], ksize) device tensors from lmx.resample.coeff_tables; None skips that pass (size unchanged)."""
+    _dev(src)
+    n, sh, sw, c = src.shape
+    if c != 3 or src.dtype != torch.uint8 or not src.is_contiguous():
+        raise LmxError("pil_resize: src must be contiguous uint8 [n,h,w,3]")
+    lib = _lib.load()
+    cur = src
+    if tab_h is not None:
+        bounds, kk, ksize = tab_h
+        tmp = torch.empty((n, sh, dw, 3), dtype=torch.uint8, device=src.device)
+        check(lib.lmx_k_pil_resize_h(_ptr(cur), _ptr(tmp), n, sh, sw, dw, _ptr(bounds), _ptr(kk), ksize,
+                                     1 if swap_rb else 0, _stream()), "lmx_k_pil_resize_h")
+        cur = tmp
+    elif swap_rb:
+        raise LmxError("pil_resize: swap_rb needs the horizontal pass")
+    if tab_v is not None:
+        bounds, kk, ksize = tab_v
+        w = cur.shape[2]
+        dst = torch.empty((n, dh, w, 3), dtype=torch.uint8, device=src.device)
+        check(lib.lmx_k_pil_resize_v(_ptr(cur), _ptr(dst), n, cur.shape[1], dh, w, _ptr(bounds), _ptr(kk), ksize,
+                                     _stream()), "lmx_k_pil_resize_v")
+        cur = dst
+    return cur
+
+
+def patchify_norm(img, top, left, gh, gw, P, lut, k_pad=None):
+    """-> f16 [n*gh*gw, k_pad or P*P*3] patch matrix (columns beyond P*P*3 zero)."""
+    _dev(img, lut)
+    n, ih, iw, c = img.shape
+    if c != 3 or img.dtype != torch.uint8 or not img.is_contiguous():
+        raise LmxError("patchify_norm: img must be contiguous uint8 [n,h,w,3]")
+    K = P * P * 3
+    ldo = k_pad or K
+    alloc = torch.zeros if ldo != K else torch.empty
+    out = alloc((n * gh * gw, ldo), dtype=torch.float16, device=img.device)
+    check(_lib.load().lmx_k_patchify_norm(_ptr(img), _ptr(out), n, ih, iw, top, left, gh, gw, P, ldo, _ptr(lut),
+                                          _stream()), "lmx_k_patchify_norm")
+    return out
+
+
+def assemble_tokens(patch, prefix, pos, B, np_, n_prefix, D):
+    _dev(patch, prefix, pos)
+    out = torch.empty((B * (np_ + n_prefix), D), dtype=torch.float32, device=patch.device)
+    check(_lib.load().lmx_k_assemble_tokens(_ptr(patch), _ptr(prefix), _ptr(pos), _ptr(out), B, np_, n_prefix, D,
+                                            _stream()), "lmx_k_assemble_tokens")
+    return out
+
+
+def token_mean(x, B, T, D):
+    _dev(x)
+    out = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    check(_lib.load().lmx_k_token_mean(_ptr(x), _DT[x.dtype], _ptr(out), B, T, D, _stream()), "lmx_k_token_mean")
+    return out
+
+
+def nms(pred, conf, iou=0.7, max_det=300, max_wh=7680.0):
+    """pred f32 [n,A,4+nc] -> (boxes [n,max_det,4], scores, cls, src, counts) on device (lmx_k_nms)."""
+    _dev(pred)
+    if pred.dtype != torch.float32 or pred.dim() != 3 or not pred.is_contiguous():
+        raise LmxError("nms: pred must be contiguous float32 [n,A,4+nc]")
+    n, A, row = pred.shape
+    lib = _lib.load()
+    ws = torch.empty((int(lib.lmx_nms_workspace_bytes(n, A)),), dtype=torch.uint8, device=pred.device)
+    boxes = torch.zeros((n, max_det, 4), dtype=torch.float32, device=pred.device)
+    scores = torch.zeros((n, max_det), dtype=torch.float32, device=pred.device)
+    cls = torch.zeros((n, max_det), dtype=torch.int32, device=pred.device)
+    src = torch.full((n, max_det), -1, dtype=torch.int32, device=pred.device)
+    counts = torch.zeros((n,), dtype=torch.int32, device=pred.device)
+    check(lib.lmx_k_nms(_ptr(pred), n, A, row - 4, float(conf), float(iou), max_det, float(max_wh), _ptr(boxes),
+                        _ptr(scores), _ptr(cls), _ptr(src), _ptr(counts), _ptr(ws), _stream()), "lmx_k_nms")
+    return boxes, scores, cls, src, counts

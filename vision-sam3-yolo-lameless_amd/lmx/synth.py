@@ -1,0 +1,31 @@
+"""Synthetic 1080p clips (BASELINE cfg#5: 5 s @ 30 fps = 150 frames of [1080,1920,3] u8): a textured
+rectangle moving over a low-pass noise background, BGR like cv2 frames.  Deterministic in (seed, frame index), pure
+numpy, so the container that writes the golden vectors and the GPU box that checks them see identical bytes."""
+import numpy as np
+
+
+def _background(rng, h, w):
+    # low-pass noise: random 1/8-resolution field, nearest-upsampled, plus fine noise
+    small = rng.integers(40, 200, (h // 8 + 1, w // 8 + 1, 3), dtype=np.int32)
+    big = np.repeat(np.repeat(small, 8, 0), 8, 1)[:h, :w]
+    fine = rng.integers(-12, 13, (h, w, 3), dtype=np.int32)
+    return np.clip(big + fine, 0, 255).astype(np.uint8)
+
+
+def synth_frame(seed, idx, h=1080, w=1920):
+    rng = np.random.default_rng([int(seed), 7919])
+    img = _background(rng, h, w).copy()
+    # moving textured box ("cow"): ~40% of the height, walks left to right
+    bh, bw = int(h * 0.42), int(w * 0.30)
+    x0 = int((w - bw) * ((idx % 150) / 149.0))
+    y0 = int(h * 0.35 + h * 0.03 * np.sin(idx / 7.0))
+    yy, xx = np.mgrid[0:bh, 0:bw]
+    tex = (96 + 64 * np.sin(xx / 9.0 + idx * 0.1) * np.cos(yy / 13.0)).astype(np.int32)
+    patch = np.stack([tex + 30, tex, tex - 30], -1)
+    spots = ((xx // 24 + yy // 24) % 3 == 0)[..., None] * 50
+    img[y0:y0 + bh, x0:x0 + bw] = np.clip(patch + spots, 0, 255).astype(np.uint8)
+    return img
+
+
+def synth_clip(seed, n_frames=150, h=1080, w=1920, start=0):
+    return np.stack([synth_frame(seed, start + i, h, w) for i in range(n_frames)], 0)
