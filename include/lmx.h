@@ -155,6 +155,32 @@ int lmx_k_nms(const float* pred, int n, int A, int nc, float conf, double iou, i
               float* boxes, float* scores, int32_t* cls, int32_t* src, int32_t* counts, void* workspace,
               lmx_stream_t stream);
 
+/* ---- YOLOv8 non-GEMM pieces (ultralytics predictor under yolo main.py:76) ---------- */
+/* K1: LetterBox = cv2.resize(INTER_LINEAR, u8 fixed point) to rh x rw + constant-114 border to oh x ow at
+ * (top,left) + BGR->RGB (swap_rb).  src u8 [n][sh][sw][3] -> dst u8 [n][oh][ow][3].  Tables from the host
+ * (lmx/letterbox.py restates OpenCV's resizeGeneric_ table build): xofs i32 [rw], ialpha i16 [rw][2], yofs i32 [rh],
+ * ibeta i16 [rh][2]; ignored (may be NULL) when rh==sh && rw==sw (LetterBox then skips the resize). */
+int lmx_k_letterbox(const uint8_t* src, uint8_t* dst, int n, int sh, int sw, int rh, int rw, int top, int left,
+                    int oh, int ow, const int32_t* xofs, const int16_t* ialpha, const int32_t* yofs,
+                    const int16_t* ibeta, int swap_rb, lmx_stream_t stream);
+/* stem Conv(3->Cout,k3,s2,p1)+bias+SiLU straight from the u8 letterboxed RGB frame (x = u8/255 in f32):
+ * w f32 [3][3][3][Cout] (ky,kx,c,co), out f16 NHWC [n][H/2][W/2][Cout]; Cout%8==0. */
+int lmx_k_stem_conv(const uint8_t* img, const float* w, const float* bias, void* out, int n, int H, int W, int Cout,
+                    lmx_stream_t stream);
+/* K5: max_pool2d(5, stride 1, pad 2) on an NHWC f16 channel slice (pixel strides lds/ldd in elements). */
+int lmx_k_maxpool5(const void* src, int64_t lds, void* dst, int64_t ldd, int n, int H, int W, int C,
+                   lmx_stream_t stream);
+/* K6: nearest x2 upsample of an NHWC f16 slice [n][H][W][C] into a slice of a [n][2H][2W][*] buffer. */
+int lmx_k_upsample2(const void* src, int64_t lds, void* dst, int64_t ldd, int n, int H, int W, int C,
+                    lmx_stream_t stream);
+/* K7: Detect decode of one level: head f32 [n][H][W][ldh >= 64+nc] (box logits side*16+bin, then class logits)
+ * -> pred f32 [n][A][4+nc] rows a_off + y*W + x: DFL softmax expectation, dist2bbox(xywh), *stride, sigmoid. */
+int lmx_k_detect_decode(const float* head, int64_t ldh, float* pred, int n, int H, int W, int nc, float stride,
+                        int a_off, int A, lmx_stream_t stream);
+/* ops.scale_boxes: boxes f32 [total][4] xyxy in place: (x - pad)/gain clipped to [0,w] x [0,h]. */
+int lmx_k_scale_boxes(float* boxes, int total, float padx, float pady, float gain, float w, float h,
+                      lmx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

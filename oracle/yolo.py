@@ -1,0 +1,227 @@
+"""oracle.yolo — fp32 CPU restatement of what ``YOLO(...)(frame, conf=...)`` computes for one frame under
+services/yolo-pipeline/app/main.py:76: LetterBox -> BGR2RGB -> /255 -> fused DetectionModel (yolov8.yaml) ->
+non_max_suppression -> scale_boxes.  TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+ultralytics / cv2 / torchvision are not installed and /root/reference holds none of their code or any detection
+vectors: PARITY UNPINNED.  What pins the restated ARCHITECTURE is the exact match of the analytic parameter counts
+(3,157,200 / 11,166,560 / 25,902,640 / 43,691,520 / 68,229,648 for n/s/m/l/x) and GFLOPs (8.7 / 28.6 / 78.9 / 165.2 /
+257.8) with the figures Ultralytics publishes (tests/test_yolo_host.py).
+Written from the public definitions: ultralytics/cfg/models/v8/yolov8.yaml, nn/modules/{conv,block,head}.py
+(Conv, Bottleneck, C2f, SPPF, Detect, DFL), utils/tal.py (make_anchors, dist2bbox), utils/ops.py, data/augment.py.
+This file walks the yaml on its own (it does not reuse lmx.yolo's launch plan); it shares only the state-dict names.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import nms as ONMS
+
+_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768), "l": (1.0, 1.0, 512),
+           "x": (1.0, 1.25, 512)}
+# [from, repeats, module, args] — yolov8.yaml
+_YAML = [
+    (-1, 1, "Conv", (64, 3, 2)), (-1, 1, "Conv", (128, 3, 2)), (-1, 3, "C2f", (128, True)), (-1, 1, "Conv", (256, 3, 2)),
+    (-1, 6, "C2f", (256, True)), (-1, 1, "Conv", (512, 3, 2)), (-1, 6, "C2f", (512, True)), (-1, 1, "Conv", (1024, 3, 2)),
+    (-1, 3, "C2f", (1024, True)), (-1, 1, "SPPF", (1024, 5)),
+    (-1, 1, "Upsample", ()), ((-1, 6), 1, "Concat", ()), (-1, 3, "C2f", (512, False)),
+    (-1, 1, "Upsample", ()), ((-1, 4), 1, "Concat", ()), (-1, 3, "C2f", (256, False)),
+    (-1, 1, "Conv", (256, 3, 2)), ((-1, 12), 1, "Concat", ()), (-1, 3, "C2f", (512, False)),
+    (-1, 1, "Conv", (512, 3, 2)), ((-1, 9), 1, "Concat", ()), (-1, 3, "C2f", (1024, False)),
+    ((15, 18, 21), 1, "Detect", ()),
+]
+
+
+def _t(sd, k):
+    v = sd[k]
+    return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+
+
+def _fused_conv(sd, name, x, k, s, act=True):
+    """Conv2d(no bias, pad k//2) + BatchNorm2d(eps 1e-3) folded (fuse_conv_and_bn) + SiLU."""
+    w = _t(sd, name + ".conv.weight")
+    g, b = _t(sd, name + ".bn.weight"), _t(sd, name + ".bn.bias")
+    mu, var = _t(sd, name + ".bn.running_mean"), _t(sd, name + ".bn.running_var")
+    scale = g / torch.sqrt(var + 1e-3)
+    y = F.conv2d(x, w * scale.view(-1, 1, 1, 1), b - mu * scale, stride=s, padding=k // 2)
+    return F.silu(y) if act else y
+
+
+def model_forward(scale, nc, sd, x):
+    """x f32 [n,3,H,W] in [0,1] -> pred f32 [n, 4+nc, A] exactly as Detect returns it in eval mode (xywh | sigmoid cls)."""
+    depth, width, max_ch = _SCALES[scale]
+
+    def ch(c):
+        return int(math.ceil(min(c, max_ch) * width / 8) * 8)
+
+    outs = []
+    for i, (frm, rep, mod, args) in enumerate(_YAML):
+        p = f"model.{i}"
+        xin = x if i == 0 else (outs[-1] if frm == -1 else None)
+        if mod == "Conv":
+            y = _fused_conv(sd, p, xin, args[1], args[2])
+        elif mod == "C2f":
+            n = max(round(rep * depth), 1)
+            y = list(_fused_conv(sd, p + ".cv1", xin, 1, 1).chunk(2, 1))
+            for j in range(n):
+                t = _fused_conv(sd, p + f".m.{j}.cv1", y[-1], 3, 1)
+                t = _fused_conv(sd, p + f".m.{j}.cv2", t, 3, 1)
+                y.append(y[-1] + t if args[1] else t)
+            y = _fused_conv(sd, p + ".cv2", torch.cat(y, 1), 1, 1)
+        elif mod == "SPPF":
+            t = _fused_conv(sd, p + ".cv1", xin, 1, 1)
+            y1 = F.max_pool2d(t, 5, 1, 2)
+            y2 = F.max_pool2d(y1, 5, 1, 2)
+            y3 = F.max_pool2d(y2, 5, 1, 2)
+            y = _fused_conv(sd, p + ".cv2", torch.cat((t, y1, y2, y3), 1), 1, 1)
+        elif mod == "Upsample":
+            y = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+        elif mod == "Concat":
+            y = torch.cat([outs[-1] if f == -1 else outs[f] for f in frm], 1)
+        elif mod == "Detect":
+            feats = [outs[f] for f in frm]
+            heads = []
+            for l, f in enumerate(feats):
+                a = _fused_conv(sd, p + f".cv2.{l}.0", f, 3, 1)
+                a = _fused_conv(sd, p + f".cv2.{l}.1", a, 3, 1)
+                a = F.conv2d(a, _t(sd, p + f".cv2.{l}.2.weight"), _t(sd, p + f".cv2.{l}.2.bias"))
+                c = _fused_conv(sd, p + f".cv3.{l}.0", f, 3, 1)
+                c = _fused_conv(sd, p + f".cv3.{l}.1", c, 3, 1)
+                c = F.conv2d(c, _t(sd, p + f".cv3.{l}.2.weight"), _t(sd, p + f".cv3.{l}.2.bias"))
+                heads.append(torch.cat((a, c), 1))
+            bsz = heads[0].shape[0]
+            no = 64 + nc
+            x_cat = torch.cat([h.view(bsz, no, -1) for h in heads], 2)
+            # make_anchors(feats, strides=(8,16,32), offset 0.5)
+            pts, strd = [], []
+            for f, s in zip(feats, (8, 16, 32)):
+                h, w = f.shape[2], f.shape[3]
+                sx = torch.arange(w, dtype=torch.float32) + 0.5
+                sy = torch.arange(h, dtype=torch.float32) + 0.5
+                gy, gx = torch.meshgrid(sy, sx, indexing="ij")
+                pts.append(torch.stack((gx, gy), -1).view(-1, 2))
+                strd.append(torch.full((h * w, 1), float(s)))
+            anchors = torch.cat(pts).transpose(0, 1)  # [2, A]
+            strides = torch.cat(strd).transpose(0, 1)  # [1, A]
+            box, cls = x_cat.split((64, nc), 1)
+            # DFL: view(b,4,16,A).transpose(2,1).softmax(1) -> conv with arange(16)
+            bq = box.view(bsz, 4, 16, -1).transpose(2, 1).softmax(1)
+            dist = (bq * torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)).sum(1)  # [b,4,A]
+            lt, rb = dist.chunk(2, 1)
+            x1y1 = anchors.unsqueeze(0) - lt
+            x2y2 = anchors.unsqueeze(0) + rb
+            dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * strides
+            y = torch.cat((dbox, cls.sigmoid()), 1)
+        outs.append(y)
+    return outs[-1]
+
+
+def letterbox_geometry(sh, sw, imgsz=640, stride=32):
+    r = min(imgsz / sh, imgsz / sw)
+    rw, rh = int(round(sw * r)), int(round(sh * r))
+    dw, dh = (imgsz - rw) % stride, (imgsz - rh) % stride
+    dw, dh = dw / 2, dh / 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return rh, rw, top, bottom, left, right
+
+
+def cv2_resize_linear_u8(img, rw, rh):
+    """OpenCV resize(INTER_LINEAR) for 8UC3, fixed point (resize.cpp: HResizeLinear<uchar,int,short,2048>,
+    VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>).  Scalar loops over the tables, vectorised over pixels."""
+    sh, sw = img.shape[:2]
+
+    def table(ssize, dsize, clamp):
+        scale = 1.0 / (float(dsize) / float(ssize))
+        ofs = np.empty(dsize, np.int64)
+        co = np.empty((dsize, 2), np.int64)
+        for d in range(dsize):
+            f = np.float32((d + 0.5) * scale - 0.5)
+            s = int(np.floor(f))
+            f = np.float32(f - np.float32(s))
+            if clamp and s < 0:
+                s, f = 0, np.float32(0)
+            if clamp and s >= ssize - 1:
+                s, f = ssize - 1, np.float32(0)
+            ofs[d] = s
+            co[d, 0] = int(np.rint(np.float32((np.float32(1) - f) * np.float32(2048))))
+            co[d, 1] = int(np.rint(np.float32(f * np.float32(2048))))
+        return ofs, co
+
+    xo, xa = table(sw, rw, True)
+    yo, yb = table(sh, rh, False)
+    src = img.astype(np.int64)
+    x1 = np.minimum(xo + 1, sw - 1)
+    hb = src[:, xo, :] * xa[None, :, 0, None] + src[:, x1, :] * xa[None, :, 1, None]
+    y0, y1 = np.clip(yo, 0, sh - 1), np.clip(yo + 1, 0, sh - 1)
+    v = (((yb[:, 0, None, None] * (hb[y0] >> 4)) >> 16) + ((yb[:, 1, None, None] * (hb[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def letterbox(frame_bgr, imgsz=640, stride=32):
+    sh, sw = frame_bgr.shape[:2]
+    rh, rw, top, bottom, left, right = letterbox_geometry(sh, sw, imgsz, stride)
+    img = frame_bgr if (rh, rw) == (sh, sw) else cv2_resize_linear_u8(frame_bgr, rw, rh)
+    out = np.full((rh + top + bottom, rw + left + right, 3), 114, np.uint8)
+    out[top:top + rh, left:left + rw] = img
+    return out
+
+
+def scale_boxes(img1_shape, boxes, img0_shape):
+    """ultralytics.utils.ops.scale_boxes + clip_boxes on f32 xyxy (numpy f32 step by step, like the torch f32 ops)."""
+    gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+    padx = round((img1_shape[1] - img0_shape[1] * gain) / 2 - 0.1)
+    pady = round((img1_shape[0] - img0_shape[0] * gain) / 2 - 0.1)
+    b = np.array(boxes, np.float32, copy=True)
+    b[:, [0, 2]] -= np.float32(padx)
+    b[:, [1, 3]] -= np.float32(pady)
+    b /= np.float32(gain)
+    b[:, [0, 2]] = np.clip(b[:, [0, 2]], 0, np.float32(img0_shape[1]))
+    b[:, [1, 3]] = np.clip(b[:, [1, 3]], 0, np.float32(img0_shape[0]))
+    return b
+
+
+def predict(scale, nc, sd, frame_bgr, conf=0.25, iou=0.7, max_det=300, imgsz=640):
+    """One frame, like the service's call: -> dict(boxes [k,4] xyxy frame px, scores, cls, src, pred [A,4+nc], lb shape)."""
+    lb = letterbox(frame_bgr, imgsz)
+    x = torch.from_numpy(np.ascontiguousarray(lb[:, :, ::-1].transpose(2, 0, 1))).float() / 255
+    with torch.no_grad():
+        pred = model_forward(scale, nc, sd, x[None])[0].transpose(0, 1).contiguous().numpy()  # [A, 4+nc]
+    boxes, scores, cls, src = ONMS.non_max_suppression(pred, conf, iou, max_det)
+    boxes = scale_boxes(lb.shape[:2], boxes, frame_bgr.shape[:2]) if len(boxes) else boxes
+    return dict(boxes=boxes, scores=scores, cls=cls, src=src, pred=pred, lb_shape=lb.shape[:2])
+
+
+def calibrate_bn(scale, nc, sd, x):
+    """Synthetic-weight hygiene (not part of the reference): random Conv+SiLU stacks either collapse or overflow f16
+    after ~60 layers, which a trained network avoids through BatchNorm.  This walks the model once on the batch ``x``
+    and sets every BatchNorm's running_mean/var to the batch statistics of its conv output (what BN training mode
+    would record), so that activations stay O(1).  Returns {bn stat name: f32 array}; tests/golden/make_golden.py
+    commits them so the container and the GPU box build identical weights."""
+    stats = {}
+    sd = dict(sd)
+
+    def conv_cal(sd_, name, xx, k, s, act=True):
+        w = _t(sd_, name + ".conv.weight")
+        z = F.conv2d(xx, w, None, stride=s, padding=k // 2)
+        mu = z.mean(dim=(0, 2, 3))
+        var = z.var(dim=(0, 2, 3), unbiased=False)
+        stats[name + ".bn.running_mean"] = mu.numpy().astype(np.float32)
+        stats[name + ".bn.running_var"] = var.numpy().astype(np.float32)
+        sd_[name + ".bn.running_mean"] = stats[name + ".bn.running_mean"]
+        sd_[name + ".bn.running_var"] = stats[name + ".bn.running_var"]
+        return _fused_conv_impl(sd_, name, xx, k, s, act)
+
+    global _fused_conv
+    saved = _fused_conv
+    _fused_conv = conv_cal
+    try:
+        with torch.no_grad():
+            model_forward(scale, nc, sd, x)
+    finally:
+        _fused_conv = saved
+    return stats
+
+
+_fused_conv_impl = _fused_conv

@@ -66,7 +66,36 @@ def make_dino(name, cfg, seed, frame_ids, clip_seed):
                         pixel_checksum=np.asarray([int(pv.double().abs().sum() * 1000)]))
 
 
+def make_yolo(scale, seed, calib_clip, frames_spec):
+    """BN calibration statistics (synthetic-weight hygiene, see oracle.yolo.calibrate_bn) + the fp32 oracle's
+    detections on a few 1080p frames.  No ultralytics/cv2 here: these are ORACLE outputs (parity unpinned)."""
+    from lmx import yolo
+    from oracle import yolo as OY
+
+    cfg = yolo.YoloConfig(scale)
+    sd = yolo.synthetic_state_dict(cfg, seed)
+    calib = [synth.synth_frame(calib_clip, i) for i in (10, 90)]
+    x = torch.stack([torch.from_numpy(np.ascontiguousarray(OY.letterbox(f)[:, :, ::-1].transpose(2, 0, 1))).float() / 255
+                     for f in calib])
+    stats = OY.calibrate_bn(scale, cfg.nc, sd, x)
+    bn_path = os.path.join(HERE, f"yolov8{scale}_bn_w{seed}.npz")
+    np.savez(bn_path, **stats)
+    sd = yolo.synthetic_state_dict(cfg, seed, bn_path)
+    out = {"weight_seed": seed, "frames": np.asarray(frames_spec)}
+    for j, (cs, fi) in enumerate(frames_spec):
+        for conf in (0.25, 0.5):
+            r = OY.predict(scale, cfg.nc, sd, synth.synth_frame(cs, fi), conf=conf)
+            tag = f"f{j}_c{int(conf * 100)}"
+            out[tag + "_boxes"], out[tag + "_scores"] = r["boxes"], r["scores"]
+            out[tag + "_cls"], out[tag + "_src"] = r["cls"], r["src"]
+        out[f"f{j}_pred_sample"] = r["pred"][::97].copy()  # every 97th anchor row of the raw prediction
+        print(f"yolov8{scale} frame {cs}/{fi}: {len(r['src'])} detections at conf 0.5")
+    np.savez_compressed(os.path.join(HERE, f"yolov8{scale}_det_w{seed}.npz"), **out)
+
+
 if __name__ == "__main__":
+    make_yolo("n", 7, 2, [(3, 40), (2, 50), (4, 0)])
+    make_yolo("l", 7, 2, [(3, 40), (2, 50)])
     torch.manual_seed(0)
     make_dino("dinov3_vitl16_w3", dino.dinov3_vitl16(), 3, [0, 75, 149], clip_seed=4)
     make_dino("dinov2_base_w4", dino.dinov2_base(), 4, [0, 30], clip_seed=5)

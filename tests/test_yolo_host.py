@@ -1,0 +1,96 @@
+"""Host-side YOLO logic (no GPU): the restated architecture reproduces Ultralytics' published parameter counts and
+GFLOPs exactly; letterbox geometry / cv2-linear tables / scale_boxes known answers; lmx's launch-plan bookkeeping
+(lmx.yolo) and the oracle's independent yaml walk (oracle.yolo) agree on every tensor name and folded weight."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lmx import letterbox as LB
+from lmx import synth, yolo
+from oracle import yolo as OY
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("scale,params,gflops", [("n", 3157200, 8.7), ("s", 11166560, 28.6), ("m", 25902640, 78.9),
+                                                  ("l", 43691520, 165.2), ("x", 68229648, 257.8)])
+def test_published_params_and_flops(scale, params, gflops):
+    p, macs = yolo.count_params_flops(yolo.YoloConfig(scale))
+    assert p == params
+    assert abs(2 * macs / 1e9 - gflops) < 0.06
+
+
+def test_letterbox_geometry_known_answers():
+    g = LB.geometry(1080, 1920)
+    assert (g.rh, g.rw, g.top, g.left, g.oh, g.ow) == (360, 640, 12, 0, 384, 640)
+    assert (g.pad_x, g.pad_y) == (0.0, 12.0) and abs(g.gain - 1 / 3) < 1e-12
+    g = LB.geometry(640, 640)
+    assert (g.rh, g.rw, g.top, g.left, g.oh, g.ow) == (640, 640, 0, 0, 640, 640)
+    g = LB.geometry(720, 1280)
+    assert (g.rh, g.rw, g.oh, g.ow, g.top) == (360, 640, 384, 640, 12)
+    g = LB.geometry(1000, 600)  # portrait: width padded to a multiple of 32
+    assert (g.rh, g.rw) == (640, 384) and g.ow == 384 and g.oh == 640
+    assert OY.letterbox_geometry(1080, 1920)[:3] == (360, 640, 12)
+
+
+@pytest.mark.parametrize("h,w", [(1080, 1920), (720, 1280), (480, 500), (300, 200)])
+def test_letterbox_restatements_agree(h, w):
+    f = synth.synth_frame(11, 3, h, w)
+    a = LB.letterbox_reference(f, LB.geometry(h, w), swap_rb=False)
+    b = OY.letterbox(f)
+    assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_cv2_linear_known_properties():
+    # constant image stays constant; exact 2x decimation of a horizontal ramp averages neighbours
+    img = np.full((64, 64, 3), 77, np.uint8)
+    assert np.all(OY.cv2_resize_linear_u8(img, 20, 30) == 77)
+    ramp = np.tile(np.arange(64, dtype=np.uint8)[None, :, None] * 4, (8, 1, 3))
+    out = OY.cv2_resize_linear_u8(ramp, 32, 8)
+    assert np.array_equal(out[0, :, 0], (ramp[0, 0::2, 0].astype(int) + ramp[0, 1::2, 0]) // 2)
+
+
+def test_scale_boxes_known_answer():
+    b = OY.scale_boxes((384, 640), np.array([[10, 12, 630, 372], [-5, 0, 700, 400]], np.float32), (1080, 1920))
+    assert np.allclose(b[0], [30, 0, 1890, 1080]) and np.allclose(b[1], [0, 0, 1920, 1080])
+
+
+def test_fold_and_names_agree_with_oracle():
+    cfg = yolo.YoloConfig("n")
+    sd = yolo.synthetic_state_dict(cfg, 7, os.path.join(GOLD, "yolov8n_bn_w7.npz"))
+    # every name the oracle touches exists, and the oracle's own fold equals lmx's
+    x = torch.rand(1, 3, 64, 64)
+    seen = []
+    orig = OY._fused_conv
+
+    def spy(sd_, name, xx, k, s, act=True):
+        seen.append(name)
+        w, b = yolo.fold_bn(sd_, name)
+        g, be = torch.from_numpy(sd_[name + ".bn.weight"]), torch.from_numpy(sd_[name + ".bn.bias"])
+        mu, var = torch.from_numpy(sd_[name + ".bn.running_mean"]), torch.from_numpy(sd_[name + ".bn.running_var"])
+        sc = g / torch.sqrt(var + 1e-3)
+        assert np.allclose(w, (torch.from_numpy(sd_[name + ".conv.weight"]) * sc.view(-1, 1, 1, 1)).numpy(), atol=1e-6)
+        assert np.allclose(b, (be - mu * sc).numpy(), atol=1e-6)
+        return orig(sd_, name, xx, k, s, act)
+
+    OY._fused_conv = spy
+    try:
+        with torch.no_grad():
+            out = OY.model_forward("n", 80, sd, x)
+    finally:
+        OY._fused_conv = orig
+    assert out.shape == (1, 84, 4 + 16 + 64)  # 64x64 input -> 8x8 + 4x4 + 2x2 anchors
+    conv_names = {k[:-len(".conv.weight")] for k in yolo.param_spec(cfg) if k.endswith(".conv.weight")}
+    assert set(seen) == conv_names
+
+
+def test_oracle_detections_match_committed_golden():
+    g = np.load(os.path.join(GOLD, "yolov8n_det_w7.npz"))
+    cfg = yolo.YoloConfig("n")
+    sd = yolo.synthetic_state_dict(cfg, int(g["weight_seed"]), os.path.join(GOLD, "yolov8n_bn_w7.npz"))
+    cs, fi = g["frames"][2]
+    r = OY.predict("n", 80, sd, synth.synth_frame(int(cs), int(fi)), conf=0.5)
+    assert np.array_equal(r["src"], g["f2_c50_src"]) and np.array_equal(r["cls"], g["f2_c50_cls"])
+    assert np.allclose(r["boxes"], g["f2_c50_boxes"], atol=1e-3) and np.allclose(r["scores"], g["f2_c50_scores"], atol=1e-6)

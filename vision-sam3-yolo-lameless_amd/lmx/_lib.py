@@ -53,6 +53,12 @@ SIGNATURES = {
     "lmx_k_token_mean": (_I, [_VP, _I, _VP, _I, _I, _I, _VP]),
     "lmx_nms_workspace_bytes": (_I64, [_I, _I]),
     "lmx_k_nms": (_I, [_VP, _I, _I, _I, _F, _D, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "lmx_k_letterbox": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _VP]),
+    "lmx_k_stem_conv": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "lmx_k_maxpool5": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
+    "lmx_k_upsample2": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
+    "lmx_k_detect_decode": (_I, [_VP, _I64, _VP, _I, _I, _I, _I, _F, _I, _I, _VP]),
+    "lmx_k_scale_boxes": (_I, [_VP, _I, _F, _F, _F, _F, _F, _VP]),
 }
 
 _lib = None

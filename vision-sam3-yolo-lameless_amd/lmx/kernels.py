@@ -244,3 +244,71 @@ def nms(pred, conf, iou=0.7, max_det=300, max_wh=7680.0):
     check(lib.lmx_k_nms(_ptr(pred), n, A, row - 4, float(conf), float(iou), max_det, float(max_wh), _ptr(boxes),
                         _ptr(scores), _ptr(cls), _ptr(src), _ptr(counts), _ptr(ws), _stream()), "lmx_k_nms")
     return boxes, scores, cls, src, counts
+
+
+# ---- YOLO pieces ------------------------------------------------------------------------------------------
+def letterbox(frames, geo, tables, swap_rb=True):
+    """u8 [n,sh,sw,3] -> u8 [n,oh,ow,3]; geo from lmx.letterbox.geometry, tables = device (xofs, ialpha, yofs, ibeta)."""
+    _dev(frames)
+    n, sh, sw, c = frames.shape
+    if c != 3 or frames.dtype != torch.uint8 or not frames.is_contiguous():
+        raise LmxError("letterbox: frames must be contiguous uint8 [n,h,w,3]")
+    out = torch.empty((n, geo.oh, geo.ow, 3), dtype=torch.uint8, device=frames.device)
+    xo, ia, yo, ib = tables if tables is not None else (None, None, None, None)
+    check(_lib.load().lmx_k_letterbox(_ptr(frames), _ptr(out), n, sh, sw, geo.rh, geo.rw, geo.top, geo.left, geo.oh, geo.ow,
+                                      _ptr(xo), _ptr(ia), _ptr(yo), _ptr(ib), 1 if swap_rb else 0, _stream()),
+          "lmx_k_letterbox")
+    return out
+
+
+def stem_conv(img_u8, w, bias, out=None):
+    _dev(img_u8, w, bias, out)
+    n, H, W, _ = img_u8.shape
+    Cout = bias.numel()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((n, Ho, Wo, Cout), dtype=torch.float16, device=img_u8.device)
+    if not out.is_contiguous() or tuple(out.shape) != (n, Ho, Wo, Cout):
+        raise LmxError("stem_conv: out must be a dense NHWC tensor")
+    check(_lib.load().lmx_k_stem_conv(_ptr(img_u8), _ptr(w), _ptr(bias), _ptr(out), n, H, W, Cout, _stream()),
+          "lmx_k_stem_conv")
+    return out
+
+
+def maxpool5(x, out):
+    n, H, W, Cc, ps = _nhwc(x, "maxpool5 x")
+    no, Ho, Wo, Co, pso = _nhwc(out, "maxpool5 out")
+    if (no, Ho, Wo, Co) != (n, H, W, Cc):
+        raise LmxError("maxpool5: shape mismatch")
+    check(_lib.load().lmx_k_maxpool5(_ptr(x), ps, _ptr(out), pso, n, H, W, Cc, _stream()), "lmx_k_maxpool5")
+    return out
+
+
+def upsample2(x, out):
+    n, H, W, Cc, ps = _nhwc(x, "upsample2 x")
+    no, Ho, Wo, Co, pso = _nhwc(out, "upsample2 out")
+    if (no, Ho, Wo, Co) != (n, 2 * H, 2 * W, Cc):
+        raise LmxError("upsample2: shape mismatch")
+    check(_lib.load().lmx_k_upsample2(_ptr(x), ps, _ptr(out), pso, n, H, W, Cc, _stream()), "lmx_k_upsample2")
+    return out
+
+
+def detect_decode(head, pred, nc, stride, a_off):
+    """head f32 [n,H,W,ldh] dense, pred f32 [n,A,4+nc] dense."""
+    _dev(head, pred)
+    n, H, W, ldh = head.shape
+    A = pred.shape[1]
+    if not head.is_contiguous() or not pred.is_contiguous() or pred.shape[2] != 4 + nc:
+        raise LmxError("detect_decode: head/pred must be dense")
+    check(_lib.load().lmx_k_detect_decode(_ptr(head), ldh, _ptr(pred), n, H, W, nc, float(stride), a_off, A, _stream()),
+          "lmx_k_detect_decode")
+    return pred
+
+
+def scale_boxes(boxes, padx, pady, gain, w, h):
+    _dev(boxes)
+    if boxes.dtype != torch.float32 or not boxes.is_contiguous() or boxes.shape[-1] != 4:
+        raise LmxError("scale_boxes: boxes must be dense float32 [...,4]")
+    check(_lib.load().lmx_k_scale_boxes(_ptr(boxes), boxes.numel() // 4, float(padx), float(pady), float(gain), float(w),
+                                        float(h), _stream()), "lmx_k_scale_boxes")
+    return boxes

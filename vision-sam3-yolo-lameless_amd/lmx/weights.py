@@ -22,6 +22,16 @@ def synth_tensor(seed, name, shape, kind):
     if kind == "w":
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
         return (r.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+    if kind.startswith("wc"):  # conv followed by SiLU: "wc@g" = normal * g / sqrt(fan_in); g = 1.68 / rms(input)
+        fan_in = int(np.prod(shape[1:]))  # (1.68 = 1/rms(silu(N(0,1))) keeps activations O(1) through ~60 layers)
+        gain = float(kind.split("@")[1]) if "@" in kind else 1.68
+        return (gain * r.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+    if kind == "var":  # BatchNorm running_var
+        return (0.5 + r.random(shape)).astype(np.float32)
+    if kind == "boxb":  # Detect box-branch bias (ultralytics bias_init sets 1.0)
+        return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)
+    if kind == "clsb":  # Detect class-branch bias: strongly negative, as in a trained detector (few positives)
+        return (-6.0 + 0.5 * r.standard_normal(shape)).astype(np.float32)
     if kind == "b":
         return (0.1 * r.standard_normal(shape)).astype(np.float32)
     if kind == "g":

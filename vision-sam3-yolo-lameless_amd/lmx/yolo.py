@@ -1,0 +1,366 @@
+"""YOLOv8 detector on liblmx — the model call of services/yolo-pipeline/app/main.py:76
+(``self.yolo_model(frame, verbose=False, conf=...)``): LetterBox -> fused Conv-BN-SiLU CSPDarknet/C2f + PAN +
+Detect(DFL) -> non_max_suppression -> scale_boxes.  Architecture restated from the public Ultralytics yolov8.yaml /
+nn.modules (the package is not installed).
+
+Layout: activations are NHWC f16.  Every C2f owns ONE buffer [n,H,W,(2+nb)*c]: cv1 writes channels [0,2c), each
+bottleneck reads the previous c-wide slice and writes the next one (shortcut fused in the GEMM epilogue), cv2 is a
+1x1 GEMM over the whole buffer.  torch.cat never happens: producers write straight into channel slices of the
+consumer's buffer (SPPF, the PAN concats and the Detect head included).
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import letterbox as LB
+
+SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768), "l": (1.0, 1.0, 512),
+          "x": (1.0, 1.25, 512)}
+BN_EPS = 1e-3
+REG_MAX = 16
+
+COCO_NAMES = ["person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light",
+              "fire hydrant", "stop sign", "parking meter", "bench", "bird", "cat", "dog", "horse", "sheep", "cow",
+              "elephant", "bear", "zebra", "giraffe", "backpack", "umbrella", "handbag", "tie", "suitcase", "frisbee",
+              "skis", "snowboard", "sports ball", "kite", "baseball bat", "baseball glove", "skateboard", "surfboard",
+              "tennis racket", "bottle", "wine glass", "cup", "fork", "knife", "spoon", "bowl", "banana", "apple",
+              "sandwich", "orange", "broccoli", "carrot", "hot dog", "pizza", "donut", "cake", "chair", "couch",
+              "potted plant", "bed", "dining table", "toilet", "tv", "laptop", "mouse", "remote", "keyboard",
+              "cell phone", "microwave", "oven", "toaster", "sink", "refrigerator", "book", "clock", "vase", "scissors",
+              "teddy bear", "hair drier", "toothbrush"]
+
+
+def _make_divisible(x, d=8):
+    return int(math.ceil(x / d) * d)
+
+
+@dataclass
+class YoloConfig:
+    scale: str = "l"
+    nc: int = 80
+    imgsz: int = 640
+
+    def ch(self, c):
+        _, width, max_ch = SCALES[self.scale]
+        return _make_divisible(min(c, max_ch) * width, 8)
+
+    def depth(self, n):
+        d, _, _ = SCALES[self.scale]
+        return max(round(n * d), 1)
+
+
+def layer_table(cfg):
+    """The 23 modules of yolov8.yaml with resolved channels: list of dicts (kind, src, c_out, ...)."""
+    c = cfg.ch
+    d = cfg.depth
+    L = [
+        dict(kind="conv", src=-1, c2=c(64), k=3, s=2),                  # 0  P1/2
+        dict(kind="conv", src=-1, c2=c(128), k=3, s=2),                 # 1  P2/4
+        dict(kind="c2f", src=-1, c2=c(128), n=d(3), shortcut=True),     # 2
+        dict(kind="conv", src=-1, c2=c(256), k=3, s=2),                 # 3  P3/8
+        dict(kind="c2f", src=-1, c2=c(256), n=d(6), shortcut=True),     # 4
+        dict(kind="conv", src=-1, c2=c(512), k=3, s=2),                 # 5  P4/16
+        dict(kind="c2f", src=-1, c2=c(512), n=d(6), shortcut=True),     # 6
+        dict(kind="conv", src=-1, c2=c(1024), k=3, s=2),                # 7  P5/32
+        dict(kind="c2f", src=-1, c2=c(1024), n=d(3), shortcut=True),    # 8
+        dict(kind="sppf", src=-1, c2=c(1024)),                          # 9
+        dict(kind="up", src=-1),                                        # 10
+        dict(kind="cat", src=(-1, 6)),                                  # 11
+        dict(kind="c2f", src=-1, c2=c(512), n=d(3), shortcut=False),    # 12
+        dict(kind="up", src=-1),                                        # 13
+        dict(kind="cat", src=(-1, 4)),                                  # 14
+        dict(kind="c2f", src=-1, c2=c(256), n=d(3), shortcut=False),    # 15 (P3/8-small)
+        dict(kind="conv", src=-1, c2=c(256), k=3, s=2),                 # 16
+        dict(kind="cat", src=(-1, 12)),                                 # 17
+        dict(kind="c2f", src=-1, c2=c(512), n=d(3), shortcut=False),    # 18 (P4/16-medium)
+        dict(kind="conv", src=-1, c2=c(512), k=3, s=2),                 # 19
+        dict(kind="cat", src=(-1, 9)),                                  # 20
+        dict(kind="c2f", src=-1, c2=c(1024), n=d(3), shortcut=False),   # 21 (P5/32-large)
+        dict(kind="detect", src=(15, 18, 21)),                          # 22
+    ]
+    # resolve input channels
+    out_c = []
+    for i, m in enumerate(L):
+        if m["kind"] in ("conv", "c2f", "sppf"):
+            m["c1"] = 3 if i == 0 else out_c[i - 1]
+            out_c.append(m["c2"])
+        elif m["kind"] == "up":
+            out_c.append(out_c[i - 1])
+        elif m["kind"] == "cat":
+            a, b = m["src"]
+            out_c.append(out_c[i - 1] + out_c[b])
+        else:
+            m["ch"] = tuple(out_c[j] for j in m["src"])
+            out_c.append(0)
+    return L
+
+
+def _conv_spec(s, name, c1, c2, k, rms_in=1.0):
+    # synthetic init only: the gain compensates the expected RMS of the conv's input (residual sums, concats, pools)
+    s[name + ".conv.weight"] = ((c2, c1, k, k), f"wc@{1.68 / rms_in:.4f}")
+    s[name + ".bn.weight"] = ((c2,), "g")
+    s[name + ".bn.bias"] = ((c2,), "b")
+    s[name + ".bn.running_mean"] = ((c2,), "b")
+    s[name + ".bn.running_var"] = ((c2,), "var")
+
+
+def param_spec(cfg):
+    """Ordered {ultralytics state-dict name: (shape, init kind)} for DetectionModel(yolov8{scale}.yaml)."""
+    s = {}
+    for i, m in enumerate(layer_table(cfg)):
+        p = f"model.{i}"
+        if m["kind"] == "conv":
+            _conv_spec(s, p, m["c1"], m["c2"], m["k"], 0.45 if i == 0 else 1.0)  # stem input: pixels/255
+        elif m["kind"] == "c2f":
+            c = m["c2"] // 2
+            nb = m["n"]
+            # mean square of the chunks [y0a, y0b, y1..yn]: with shortcuts y_j = y_{j-1} + t_j grows like 1 + j
+            ms = [1.0, 1.0] + [(1.0 + j if m["shortcut"] else 1.0) for j in range(1, nb + 1)]
+            _conv_spec(s, p + ".cv1", m["c1"], 2 * c, 1)
+            _conv_spec(s, p + ".cv2", (2 + nb) * c, m["c2"], 1, math.sqrt(sum(ms) / len(ms)))
+            for j in range(nb):
+                _conv_spec(s, p + f".m.{j}.cv1", c, c, 3, math.sqrt(ms[1 + j]))
+                _conv_spec(s, p + f".m.{j}.cv2", c, c, 3)
+        elif m["kind"] == "sppf":
+            c_ = m["c1"] // 2
+            _conv_spec(s, p + ".cv1", m["c1"], c_, 1)
+            _conv_spec(s, p + ".cv2", c_ * 4, m["c2"], 1, 1.6)  # chained 5x5 max pools of SiLU outputs
+        elif m["kind"] == "detect":
+            ch = m["ch"]
+            c2 = max(16, ch[0] // 4, REG_MAX * 4)
+            c3 = max(ch[0], min(cfg.nc, 100))
+            for l, x in enumerate(ch):
+                _conv_spec(s, p + f".cv2.{l}.0", x, c2, 3)
+                _conv_spec(s, p + f".cv2.{l}.1", c2, c2, 3)
+                s[p + f".cv2.{l}.2.weight"] = ((4 * REG_MAX, c2, 1, 1), "w")
+                s[p + f".cv2.{l}.2.bias"] = ((4 * REG_MAX,), "boxb")
+                _conv_spec(s, p + f".cv3.{l}.0", x, c3, 3)
+                _conv_spec(s, p + f".cv3.{l}.1", c3, c3, 3)
+                s[p + f".cv3.{l}.2.weight"] = ((cfg.nc, c3, 1, 1), "w")
+                s[p + f".cv3.{l}.2.bias"] = ((cfg.nc,), "clsb")
+    return s
+
+
+def synthetic_state_dict(cfg, seed, bn_stats=None):
+    """Synthetic YOLOv8 weights: the seeded generator plus (optionally) committed BatchNorm running statistics
+    (tests/golden/yolov8*_bn_w*.npz, produced once on the CPU by tests/golden/make_golden.py): random Conv+SiLU stacks
+    are not stable over ~60 layers without the statistics a trained BatchNorm carries."""
+    from . import weights
+
+    sd = weights.synth_state_dict(param_spec(cfg), seed)
+    if bn_stats is not None:
+        stats = np.load(bn_stats) if isinstance(bn_stats, str) else bn_stats
+        for k in stats.files if hasattr(stats, "files") else stats:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                if sd[k].shape != stats[k].shape:
+                    raise ValueError(f"BN stat {k}: shape {stats[k].shape} != {sd[k].shape}")
+                sd[k] = np.asarray(stats[k], np.float32)
+    return sd
+
+
+def fold_bn(sd, name):
+    """ultralytics.utils.torch_utils.fuse_conv_and_bn: w' = w * g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)."""
+    w = sd[name + ".conv.weight"].astype(np.float32)
+    g, b = sd[name + ".bn.weight"], sd[name + ".bn.bias"]
+    mu, var = sd[name + ".bn.running_mean"], sd[name + ".bn.running_var"]
+    s = (g / np.sqrt(var + np.float32(BN_EPS))).astype(np.float32)
+    return (w * s[:, None, None, None]).astype(np.float32), (b - mu * s).astype(np.float32)
+
+
+def count_params_flops(cfg, h=640, w=640):
+    """Analytic parameter count (unfused, as Ultralytics reports) and MACs of the conv stack — cross-checks the
+    restated architecture against the published 43.7 M / 165.2 GFLOPs (l) and 3.2 M / 8.7 GFLOPs (n)."""
+    spec = param_spec(cfg)
+    params = sum(int(np.prod(shape)) for name, (shape, _) in spec.items() if "running" not in name)
+    params += REG_MAX  # Detect.dfl conv (frozen arange)
+    macs = 0
+    res = {}
+    hw = (h, w)
+    for i, m in enumerate(layer_table(cfg)):
+        if m["kind"] == "conv":
+            hw = ((hw[0] - 1) // 2 + 1, (hw[1] - 1) // 2 + 1)
+            macs += hw[0] * hw[1] * m["c2"] * m["c1"] * 9
+        elif m["kind"] == "c2f":
+            c = m["c2"] // 2
+            px = hw[0] * hw[1]
+            macs += px * (m["c1"] * 2 * c + (2 + m["n"]) * c * m["c2"] + m["n"] * 2 * 9 * c * c)
+        elif m["kind"] == "sppf":
+            c_ = m["c1"] // 2
+            macs += hw[0] * hw[1] * (m["c1"] * c_ + 4 * c_ * m["c2"])
+        elif m["kind"] == "up":
+            hw = (hw[0] * 2, hw[1] * 2)
+        elif m["kind"] == "cat":
+            hw = res[m["src"][1]]
+        elif m["kind"] == "detect":
+            c2 = max(16, m["ch"][0] // 4, REG_MAX * 4)
+            c3 = max(m["ch"][0], min(cfg.nc, 100))
+            for x, j in zip(m["ch"], m["src"]):
+                px = res[j][0] * res[j][1]
+                macs += px * (9 * x * c2 + 9 * c2 * c2 + c2 * 64 + 9 * x * c3 + 9 * c3 * c3 + c3 * cfg.nc)
+        res[i] = hw
+    return params, macs
+
+
+class YoloDetector:
+    """Device-resident fused YOLOv8.  ``detect(frames_bgr_u8)`` reproduces the predictor call per frame, batched."""
+
+    def __init__(self, cfg, state_dict, device="cuda", names=None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.names = {i: n for i, n in enumerate(names if names is not None else
+                                                 (COCO_NAMES if cfg.nc == 80 else [f"class_{i}" for i in range(cfg.nc)]))}
+        self.table = layer_table(cfg)
+        self.nc_pad = (cfg.nc + 3) // 4 * 4
+        sd = state_dict
+        dev = self.device
+
+        def pack3(name):  # 3x3 conv -> [Cout, (ky,kx,ci)] f16 + f32 bias
+            w, b = fold_bn(sd, name)
+            wp = np.transpose(w, (0, 2, 3, 1)).reshape(w.shape[0], -1)
+            return (torch.from_numpy(np.ascontiguousarray(wp)).to(dev).half().contiguous(), torch.from_numpy(b).to(dev))
+
+        def pack1(name):
+            w, b = fold_bn(sd, name)
+            return (torch.from_numpy(np.ascontiguousarray(w[:, :, 0, 0])).to(dev).half().contiguous(),
+                    torch.from_numpy(b).to(dev))
+
+        self.w = {}
+        for i, m in enumerate(self.table):
+            p = f"model.{i}"
+            if m["kind"] == "conv":
+                if i == 0:
+                    w, b = fold_bn(sd, p)  # stem stays f32: [ky][kx][c][Cout]
+                    self.w[p] = (torch.from_numpy(np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)))).to(dev),
+                                 torch.from_numpy(b).to(dev))
+                else:
+                    self.w[p] = pack3(p)
+            elif m["kind"] == "c2f":
+                self.w[p + ".cv1"] = pack1(p + ".cv1")
+                self.w[p + ".cv2"] = pack1(p + ".cv2")
+                for j in range(m["n"]):
+                    self.w[p + f".m.{j}.cv1"] = pack3(p + f".m.{j}.cv1")
+                    self.w[p + f".m.{j}.cv2"] = pack3(p + f".m.{j}.cv2")
+            elif m["kind"] == "sppf":
+                self.w[p + ".cv1"] = pack1(p + ".cv1")
+                self.w[p + ".cv2"] = pack1(p + ".cv2")
+            elif m["kind"] == "detect":
+                for l in range(3):
+                    for br in ("cv2", "cv3"):
+                        self.w[p + f".{br}.{l}.0"] = pack3(p + f".{br}.{l}.0")
+                        self.w[p + f".{br}.{l}.1"] = pack3(p + f".{br}.{l}.1")
+                        w = sd[p + f".{br}.{l}.2.weight"][:, :, 0, 0].astype(np.float32)
+                        b = sd[p + f".{br}.{l}.2.bias"].astype(np.float32)
+                        if br == "cv3" and self.nc_pad != cfg.nc:  # pad class rows to a multiple of 4 (GEMM N%4)
+                            w = np.concatenate([w, np.zeros((self.nc_pad - cfg.nc, w.shape[1]), np.float32)], 0)
+                            b = np.concatenate([b, np.zeros((self.nc_pad - cfg.nc,), np.float32)], 0)
+                        self.w[p + f".{br}.{l}.2"] = (torch.from_numpy(np.ascontiguousarray(w)).to(dev).half().contiguous(),
+                                                      torch.from_numpy(b).to(dev))
+        self._tabs = {}
+
+    # ---- network --------------------------------------------------------------------------------------------
+    def _c2f(self, i, m, x, out):
+        p = f"model.{i}"
+        n, H, W, _ = x.shape
+        c = m["c2"] // 2
+        buf = torch.empty((n, H, W, (2 + m["n"]) * c), dtype=torch.float16, device=x.device)
+        K.conv1x1(x, *self.w[p + ".cv1"], act=K.ACT_SILU, out=buf[..., :2 * c])
+        tmp = torch.empty((n, H, W, c), dtype=torch.float16, device=x.device)
+        for j in range(m["n"]):
+            src = buf[..., (1 + j) * c:(2 + j) * c]
+            dst = buf[..., (2 + j) * c:(3 + j) * c]
+            K.conv3x3(src, *self.w[p + f".m.{j}.cv1"], act=K.ACT_SILU, out=tmp)
+            K.conv3x3(tmp, *self.w[p + f".m.{j}.cv2"], act=K.ACT_SILU, res=src if m["shortcut"] else None, out=dst)
+        return K.conv1x1(buf, *self.w[p + ".cv2"], act=K.ACT_SILU, out=out)
+
+    def _sppf(self, i, m, x, out):
+        p = f"model.{i}"
+        n, H, W, _ = x.shape
+        c_ = m["c1"] // 2
+        buf = torch.empty((n, H, W, 4 * c_), dtype=torch.float16, device=x.device)
+        K.conv1x1(x, *self.w[p + ".cv1"], act=K.ACT_SILU, out=buf[..., :c_])
+        for j in range(3):
+            K.maxpool5(buf[..., j * c_:(j + 1) * c_], buf[..., (j + 1) * c_:(j + 2) * c_])
+        return K.conv1x1(buf, *self.w[p + ".cv2"], act=K.ACT_SILU, out=out)
+
+    def forward_letterboxed(self, img_u8):
+        """u8 RGB letterboxed [n,H,W,3] (H,W multiples of 32) -> pred f32 [n, A, 4+nc] (xywh in input pixels, scores)."""
+        cfg, T = self.cfg, self.table
+        dev = img_u8.device
+        n, H, W, _ = img_u8.shape
+        f16 = torch.float16
+
+        def buf(h, w, c):
+            return torch.empty((n, h, w, c), dtype=f16, device=dev)
+
+        c_out = [m.get("c2", 0) for m in T]
+        H8, W8, H16, W16, H32, W32 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
+        # concat buffers (producer slices): cat11 = [up(9) | 6], cat14 = [up(12) | 4], cat17 = [16 | 12], cat20 = [19 | 9]
+        c4, c6, c9, c12 = c_out[4], c_out[6], c_out[9], c_out[12]
+        c16, c19 = c_out[16], c_out[19]
+        cat11 = buf(H16, W16, c9 + c6)
+        cat14 = buf(H8, W8, c12 + c4)
+        cat17 = buf(H16, W16, c16 + c12)
+        cat20 = buf(H32, W32, c19 + c9)
+        x = K.stem_conv(img_u8, *self.w["model.0"])                                            # 0
+        x = K.conv3x3(x, *self.w["model.1"], act=K.ACT_SILU, stride=2)                          # 1
+        x = self._c2f(2, T[2], x, buf(H // 4, W // 4, c_out[2]))                               # 2
+        x = K.conv3x3(x, *self.w["model.3"], act=K.ACT_SILU, stride=2)                          # 3
+        x4 = self._c2f(4, T[4], x, cat14[..., c12:])                                           # 4 -> cat14
+        x = K.conv3x3(x4, *self.w["model.5"], act=K.ACT_SILU, stride=2)                         # 5
+        x6 = self._c2f(6, T[6], x, cat11[..., c9:])                                            # 6 -> cat11
+        x = K.conv3x3(x6, *self.w["model.7"], act=K.ACT_SILU, stride=2)                         # 7
+        x = self._c2f(8, T[8], x, buf(H32, W32, c_out[8]))                                     # 8
+        x9 = self._sppf(9, T[9], x, cat20[..., c19:])                                          # 9 -> cat20
+        K.upsample2(x9, cat11[..., :c9])                                                       # 10, 11
+        x12 = self._c2f(12, T[12], cat11, cat17[..., c16:])                                    # 12 -> cat17
+        K.upsample2(x12, cat14[..., :c12])                                                     # 13, 14
+        p3 = self._c2f(15, T[15], cat14, buf(H8, W8, c_out[15]))                               # 15
+        K.conv3x3(p3, *self.w["model.16"], act=K.ACT_SILU, stride=2, out=cat17[..., :c16])      # 16, 17
+        p4 = self._c2f(18, T[18], cat17, buf(H16, W16, c_out[18]))                             # 18
+        K.conv3x3(p4, *self.w["model.19"], act=K.ACT_SILU, stride=2, out=cat20[..., :c19])      # 19, 20
+        p5 = self._c2f(21, T[21], cat20, buf(H32, W32, c_out[21]))                             # 21
+        # Detect
+        A = H8 * W8 + H16 * W16 + H32 * W32
+        pred = torch.empty((n, A, 4 + cfg.nc), dtype=torch.float32, device=dev)
+        a_off = 0
+        ldh = 64 + self.nc_pad
+        for l, (feat, stride) in enumerate(((p3, 8), (p4, 16), (p5, 32))):
+            p = f"model.22"
+            h, w = feat.shape[1], feat.shape[2]
+            head = torch.empty((n, h, w, ldh), dtype=torch.float32, device=dev)
+            t = K.conv3x3(feat, *self.w[p + f".cv2.{l}.0"], act=K.ACT_SILU)
+            t = K.conv3x3(t, *self.w[p + f".cv2.{l}.1"], act=K.ACT_SILU)
+            K.conv1x1(t, *self.w[p + f".cv2.{l}.2"], act=K.ACT_NONE, out=head[..., :64])
+            t = K.conv3x3(feat, *self.w[p + f".cv3.{l}.0"], act=K.ACT_SILU)
+            t = K.conv3x3(t, *self.w[p + f".cv3.{l}.1"], act=K.ACT_SILU)
+            K.conv1x1(t, *self.w[p + f".cv3.{l}.2"], act=K.ACT_NONE, out=head[..., 64:])
+            K.detect_decode(head, pred, cfg.nc, stride, a_off)
+            a_off += h * w
+        return pred
+
+    # ---- pre / post ------------------------------------------------------------------------------------------
+    def _letterbox_tables(self, sh, sw):
+        key = (sh, sw)
+        if key not in self._tabs:
+            geo = LB.geometry(sh, sw, self.cfg.imgsz, 32, auto=True)
+            tabs = None
+            if (geo.rh, geo.rw) != (sh, sw):
+                tabs = tuple(torch.from_numpy(t).to(self.device) for t in LB.resize_tables(sh, sw, geo.rh, geo.rw))
+            self._tabs[key] = (geo, tabs)
+        return self._tabs[key]
+
+    def preprocess(self, frames_bgr):
+        _, sh, sw, _ = frames_bgr.shape
+        geo, tabs = self._letterbox_tables(sh, sw)
+        return K.letterbox(frames_bgr, geo, tabs, swap_rb=True), geo
+
+    def detect(self, frames_bgr, conf=0.25, iou=0.7, max_det=300):
+        """u8 BGR [n,h,w,3] on device -> (boxes [n,max_det,4] xyxy in FRAME pixels, scores, cls, src, counts) on device."""
+        img, geo = self.preprocess(frames_bgr)
+        pred = self.forward_letterboxed(img)
+        boxes, scores, cls, src, counts = K.nms(pred, conf, iou, max_det)
+        K.scale_boxes(boxes, geo.pad_x, geo.pad_y, geo.gain, geo.sw, geo.sh)
+        return boxes, scores, cls, src, counts
