@@ -38,18 +38,43 @@ def _t(sd, k):
     return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
 
 
+_EMULATE_F16 = False  # see model_forward(emulate_f16=True)
+
+
+def _q(x):
+    """f16 storage emulation: round to half and back (identity in the plain fp32 oracle)."""
+    return x.half().float() if _EMULATE_F16 else x
+
+
 def _fused_conv(sd, name, x, k, s, act=True):
     """Conv2d(no bias, pad k//2) + BatchNorm2d(eps 1e-3) folded (fuse_conv_and_bn) + SiLU."""
     w = _t(sd, name + ".conv.weight")
     g, b = _t(sd, name + ".bn.weight"), _t(sd, name + ".bn.bias")
     mu, var = _t(sd, name + ".bn.running_mean"), _t(sd, name + ".bn.running_var")
     scale = g / torch.sqrt(var + 1e-3)
-    y = F.conv2d(x, w * scale.view(-1, 1, 1, 1), b - mu * scale, stride=s, padding=k // 2)
+    wf = w * scale.view(-1, 1, 1, 1)
+    if _EMULATE_F16 and name != "model.0":  # the stem keeps f32 weights (VALU kernel); all other weights are f16
+        wf = _q(wf)
+    y = F.conv2d(x, wf, b - mu * scale, stride=s, padding=k // 2)
     return F.silu(y) if act else y
 
 
-def model_forward(scale, nc, sd, x):
-    """x f32 [n,3,H,W] in [0,1] -> pred f32 [n, 4+nc, A] exactly as Detect returns it in eval mode (xywh | sigmoid cls)."""
+def model_forward(scale, nc, sd, x, emulate_f16=False):
+    """x f32 [n,3,H,W] in [0,1] -> pred f32 [n, 4+nc, A] exactly as Detect returns it in eval mode (xywh | sigmoid cls).
+
+    emulate_f16=True is a SECOND checker, not the parity target: the same fp32 arithmetic with weights and every
+    stored activation rounded to half precision where the HIP path stores f16.  It separates "the kernels compute
+    something else" (must agree to ~1e-3) from "f16 storage perturbs a deep network" (measured against the plain fp32
+    run and reported)."""
+    global _EMULATE_F16
+    _EMULATE_F16 = bool(emulate_f16)
+    try:
+        return _model_forward(scale, nc, sd, x)
+    finally:
+        _EMULATE_F16 = False
+
+
+def _model_forward(scale, nc, sd, x):
     depth, width, max_ch = _SCALES[scale]
 
     def ch(c):
@@ -60,21 +85,21 @@ def model_forward(scale, nc, sd, x):
         p = f"model.{i}"
         xin = x if i == 0 else (outs[-1] if frm == -1 else None)
         if mod == "Conv":
-            y = _fused_conv(sd, p, xin, args[1], args[2])
+            y = _q(_fused_conv(sd, p, xin, args[1], args[2]))
         elif mod == "C2f":
             n = max(round(rep * depth), 1)
-            y = list(_fused_conv(sd, p + ".cv1", xin, 1, 1).chunk(2, 1))
+            y = list(_q(_fused_conv(sd, p + ".cv1", xin, 1, 1)).chunk(2, 1))
             for j in range(n):
-                t = _fused_conv(sd, p + f".m.{j}.cv1", y[-1], 3, 1)
+                t = _q(_fused_conv(sd, p + f".m.{j}.cv1", y[-1], 3, 1))
                 t = _fused_conv(sd, p + f".m.{j}.cv2", t, 3, 1)
-                y.append(y[-1] + t if args[1] else t)
-            y = _fused_conv(sd, p + ".cv2", torch.cat(y, 1), 1, 1)
+                y.append(_q(y[-1] + t if args[1] else t))
+            y = _q(_fused_conv(sd, p + ".cv2", torch.cat(y, 1), 1, 1))
         elif mod == "SPPF":
-            t = _fused_conv(sd, p + ".cv1", xin, 1, 1)
+            t = _q(_fused_conv(sd, p + ".cv1", xin, 1, 1))
             y1 = F.max_pool2d(t, 5, 1, 2)
             y2 = F.max_pool2d(y1, 5, 1, 2)
             y3 = F.max_pool2d(y2, 5, 1, 2)
-            y = _fused_conv(sd, p + ".cv2", torch.cat((t, y1, y2, y3), 1), 1, 1)
+            y = _q(_fused_conv(sd, p + ".cv2", torch.cat((t, y1, y2, y3), 1), 1, 1))
         elif mod == "Upsample":
             y = F.interpolate(xin, scale_factor=2.0, mode="nearest")
         elif mod == "Concat":
@@ -83,12 +108,12 @@ def model_forward(scale, nc, sd, x):
             feats = [outs[f] for f in frm]
             heads = []
             for l, f in enumerate(feats):
-                a = _fused_conv(sd, p + f".cv2.{l}.0", f, 3, 1)
-                a = _fused_conv(sd, p + f".cv2.{l}.1", a, 3, 1)
-                a = F.conv2d(a, _t(sd, p + f".cv2.{l}.2.weight"), _t(sd, p + f".cv2.{l}.2.bias"))
-                c = _fused_conv(sd, p + f".cv3.{l}.0", f, 3, 1)
-                c = _fused_conv(sd, p + f".cv3.{l}.1", c, 3, 1)
-                c = F.conv2d(c, _t(sd, p + f".cv3.{l}.2.weight"), _t(sd, p + f".cv3.{l}.2.bias"))
+                a = _q(_fused_conv(sd, p + f".cv2.{l}.0", f, 3, 1))
+                a = _q(_fused_conv(sd, p + f".cv2.{l}.1", a, 3, 1))
+                a = F.conv2d(a, _q(_t(sd, p + f".cv2.{l}.2.weight")), _t(sd, p + f".cv2.{l}.2.bias"))
+                c = _q(_fused_conv(sd, p + f".cv3.{l}.0", f, 3, 1))
+                c = _q(_fused_conv(sd, p + f".cv3.{l}.1", c, 3, 1))
+                c = F.conv2d(c, _q(_t(sd, p + f".cv3.{l}.2.weight")), _t(sd, p + f".cv3.{l}.2.bias"))
                 heads.append(torch.cat((a, c), 1))
             bsz = heads[0].shape[0]
             no = 64 + nc
@@ -182,12 +207,12 @@ def scale_boxes(img1_shape, boxes, img0_shape):
     return b
 
 
-def predict(scale, nc, sd, frame_bgr, conf=0.25, iou=0.7, max_det=300, imgsz=640):
+def predict(scale, nc, sd, frame_bgr, conf=0.25, iou=0.7, max_det=300, imgsz=640, emulate_f16=False):
     """One frame, like the service's call: -> dict(boxes [k,4] xyxy frame px, scores, cls, src, pred [A,4+nc], lb shape)."""
     lb = letterbox(frame_bgr, imgsz)
     x = torch.from_numpy(np.ascontiguousarray(lb[:, :, ::-1].transpose(2, 0, 1))).float() / 255
     with torch.no_grad():
-        pred = model_forward(scale, nc, sd, x[None])[0].transpose(0, 1).contiguous().numpy()  # [A, 4+nc]
+        pred = model_forward(scale, nc, sd, x[None], emulate_f16)[0].transpose(0, 1).contiguous().numpy()  # [A, 4+nc]
     boxes, scores, cls, src = ONMS.non_max_suppression(pred, conf, iou, max_det)
     boxes = scale_boxes(lb.shape[:2], boxes, frame_bgr.shape[:2]) if len(boxes) else boxes
     return dict(boxes=boxes, scores=scores, cls=cls, src=src, pred=pred, lb_shape=lb.shape[:2])

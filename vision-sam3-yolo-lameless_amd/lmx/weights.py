@@ -26,12 +26,14 @@ def synth_tensor(seed, name, shape, kind):
         fan_in = int(np.prod(shape[1:]))  # (1.68 = 1/rms(silu(N(0,1))) keeps activations O(1) through ~60 layers)
         gain = float(kind.split("@")[1]) if "@" in kind else 1.68
         return (gain * r.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+    if kind == "bnb":  # BatchNorm beta > 0: SiLU mostly in its near-linear range, so that a random 60-layer stack
+        return (1.0 + 0.3 * r.standard_normal(shape)).astype(np.float32)  # does not amplify rounding chaotically
     if kind == "var":  # BatchNorm running_var
         return (0.5 + r.random(shape)).astype(np.float32)
     if kind == "boxb":  # Detect box-branch bias (ultralytics bias_init sets 1.0)
         return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)
     if kind == "clsb":  # Detect class-branch bias: strongly negative, as in a trained detector (few positives)
-        return (-6.0 + 0.5 * r.standard_normal(shape)).astype(np.float32)
+        return (-5.0 + 0.5 * r.standard_normal(shape)).astype(np.float32)
     if kind == "b":
         return (0.1 * r.standard_normal(shape)).astype(np.float32)
     if kind == "g":

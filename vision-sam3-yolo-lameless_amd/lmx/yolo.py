@@ -102,7 +102,7 @@ def _conv_spec(s, name, c1, c2, k, rms_in=1.0):
     # synthetic init only: the gain compensates the expected RMS of the conv's input (residual sums, concats, pools)
     s[name + ".conv.weight"] = ((c2, c1, k, k), f"wc@{1.68 / rms_in:.4f}")
     s[name + ".bn.weight"] = ((c2,), "g")
-    s[name + ".bn.bias"] = ((c2,), "b")
+    s[name + ".bn.bias"] = ((c2,), "bnb")
     s[name + ".bn.running_mean"] = ((c2,), "b")
     s[name + ".bn.running_var"] = ((c2,), "var")
 
