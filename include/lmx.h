@@ -68,6 +68,9 @@ typedef struct {
   int32_t a_mode;
   /* a_mode 1 only */
   int32_t H, W_, Cin, conv_stride, Ho, Wo;
+  /* residual broadcast: if res_rows > 0 the residual row is (m % res_rows) — e.g. a position table [tokens][N]
+   * added to every image of the batch (Hiera patch embed + pos_embed, TF sam2 :661-662) */
+  int32_t res_rows;
 } lmx_gemm_desc;
 int lmx_k_gemm(const lmx_gemm_desc* d, lmx_stream_t stream);
 
@@ -180,6 +183,21 @@ int lmx_k_detect_decode(const float* head, int64_t ldh, float* pred, int n, int 
 /* ops.scale_boxes: boxes f32 [total][4] xyxy in place: (x - pad)/gain clipped to [0,w] x [0,h]. */
 int lmx_k_scale_boxes(float* boxes, int total, float padx, float pady, float gain, float w, float h,
                       lmx_stream_t stream);
+
+/* ---- SAM / Hiera non-GEMM pieces ------------------------------------------------------------------------ */
+/* K9+K10: im2col of the Hiera patch-embed conv (k7 s4 p3, TF sam2 :120-136) fused with SamPredictor's
+ * normalisation and zero padding: img u8 [n][rh][rw][3] (the PIL-resized frame) sits at the top-left of an
+ * IH x IW canvas of zeros (in NORMALISED space); out f16 [n*OH*OW][ldo], column (ky*KW + kx)*3 + c =
+ * lut[c][u8] or 0 outside the image.  OH = (IH + 2*pad - KH)/stride + 1.  ldo%8==0, ldo >= KH*KW*3 (tail zeroed). */
+int lmx_k_im2col_u8(const uint8_t* img, const float* lut, void* out, int n, int rh, int rw, int IH, int IW, int KH,
+                    int KW, int stride, int pad, int64_t ldo, lmx_stream_t stream);
+/* 2x2 / stride-2 max pool on an NHWC grid (Hiera do_pool, TF sam2 :291-300), dtype f16 or f32, channel slices
+ * allowed on both sides (pixel strides lds/ldd in elements).  H, W even. */
+int lmx_k_maxpool2(const void* src, int64_t lds, void* dst, int64_t ldd, int dtype, int n, int H, int W, int C,
+                   lmx_stream_t stream);
+/* f32 -> f16 row-wise convert (stage outputs of the f32 residual stream feeding the FPN 1x1 convs). */
+int lmx_k_cast_f32_f16(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int cols,
+                       lmx_stream_t stream);
 
 #ifdef __cplusplus
 }

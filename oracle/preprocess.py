@@ -37,3 +37,27 @@ def dino_pixel_values(frame_bgr, edge=256, crop=224):
     x = (img.astype(np.float64) * (1 / 255)).astype(np.float32)
     x = (x - np.array(IMAGENET_MEAN, np.float32)) / np.array(IMAGENET_STD, np.float32)
     return np.ascontiguousarray(x.transpose(2, 0, 1))
+
+
+SAM_PIXEL_MEAN = (123.675, 116.28, 103.53)
+SAM_PIXEL_STD = (58.395, 57.12, 57.375)
+
+
+def sam_resized_u8(frame, target=1024):
+    """segment_anything ResizeLongestSide.apply_image: np.array(resize(to_pil_image(image), (nh, nw))) — torchvision's
+    resize on a PIL image is PIL.Image.resize(..., BILINEAR).  The frame is used AS GIVEN (the sam3 service passes the
+    cv2 BGR frame to set_image without conversion: services/sam3-pipeline/app/main.py:80,193,210)."""
+    h, w = frame.shape[:2]
+    scale = target * 1.0 / max(h, w)
+    nh, nw = int(h * scale + 0.5), int(w * scale + 0.5)
+    return np.asarray(Image.fromarray(np.ascontiguousarray(frame)).resize((nw, nh), Image.BILINEAR))
+
+
+def sam_pixel_values(frame, target=1024):
+    """SamPredictor.set_image -> Sam.preprocess: (x - pixel_mean) / pixel_std on the f32 image, zero pad to target^2.
+    -> f32 [3, target, target]."""
+    img = sam_resized_u8(frame, target).astype(np.float32)
+    x = (img - np.array(SAM_PIXEL_MEAN, np.float32)) / np.array(SAM_PIXEL_STD, np.float32)
+    out = np.zeros((target, target, 3), np.float32)
+    out[:x.shape[0], :x.shape[1]] = x
+    return np.ascontiguousarray(out.transpose(2, 0, 1))

@@ -93,9 +93,32 @@ def make_yolo(scale, seed, calib_clip, frames_spec):
     np.savez_compressed(os.path.join(HERE, f"yolov8{scale}_det_w{seed}.npz"), **out)
 
 
+def make_hiera(seed, clip_seed, frame_ids):
+    """fp32 oracle (oracle.hiera, pinned to transformers' Sam2VisionModel by tests/test_oracle_hiera.py) on raw frames."""
+    from lmx import sam
+    from oracle import hiera as OH
+
+    cfg = sam.hiera_b_plus()
+    sd = weights.synth_state_dict(sam.param_spec(cfg), seed)
+    frames = [synth.synth_frame(clip_seed, i) for i in frame_ids]
+    pv = torch.from_numpy(np.stack([OP.sam_pixel_values(f, 1024) for f in frames], 0))
+    with torch.no_grad():
+        fpn, stages = OH.encoder_forward(cfg, sd, pv)
+    np.savez_compressed(os.path.join(HERE, f"hiera_bplus_w{seed}.npz"), weight_seed=seed, clip_seed=clip_seed,
+                        frame_ids=np.asarray(frame_ids),  # spatially subsampled, f16: keeps the fixture ~1 MB
+                        fpn2=fpn[2].permute(0, 2, 3, 1)[:, ::2, ::2].numpy().astype(np.float16),
+                        stage3=stages[3][:, ::2, ::2].numpy().astype(np.float16),
+                        fpn0_sub=fpn[0].permute(0, 2, 3, 1)[:, ::16, ::16].numpy().astype(np.float16))
+    print("hiera-b+ golden:", [tuple(f.shape) for f in fpn], "rms fpn2", float(fpn[2].pow(2).mean().sqrt()))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "hiera":
+        make_hiera(5, 6, [20])
+        sys.exit(0)
     make_yolo("n", 7, 2, [(3, 40), (2, 50), (4, 0)])
     make_yolo("l", 7, 2, [(3, 40), (2, 50)])
     torch.manual_seed(0)
     make_dino("dinov3_vitl16_w3", dino.dinov3_vitl16(), 3, [0, 75, 149], clip_seed=4)
     make_dino("dinov2_base_w4", dino.dinov2_base(), 4, [0, 30], clip_seed=5)
+    make_hiera(5, 6, [20])

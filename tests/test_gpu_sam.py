@@ -1,0 +1,123 @@
+"""GPU parity of the SAM image-encoder path (predictor.set_image, services/sam3-pipeline/app/main.py:80) through the
+C-ABI: byte-exact preprocessing, per-kernel checks of the Hiera glue kernels, the Hiera trunk + FPN stage by stage
+against the fp32 oracle (tiny config with every code path, and Hiera-B+ against the committed golden)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm()), float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+
+
+def test_glue_kernels(cuda):
+    from lmx import kernels as K
+
+    # 2x2 max pool, f16 slice and f32
+    x = _rand((2, 8, 12, 48), 1).half()
+    d = x.to(cuda)
+    out = torch.zeros((2, 4, 6, 16), dtype=torch.float16, device=cuda)
+    K.maxpool2(d[..., 16:32], out)
+    ref = F.max_pool2d(x[..., 16:32].float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(out.float().cpu(), ref)
+    xf = _rand((1, 6, 6, 8), 2)
+    of = torch.zeros((1, 3, 3, 8), dtype=torch.float32, device=cuda)
+    K.maxpool2(xf.to(cuda), of)
+    assert torch.equal(of.cpu(), F.max_pool2d(xf.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1))
+    # cast
+    y = _rand((37, 112), 3, 50.0)
+    assert torch.equal(K.cast_f16(y.to(cuda)).cpu(), y.half())
+    # residual broadcast in the GEMM epilogue (position table)
+    a, w = _rand((3 * 40, 64), 4).half(), _rand((32, 64), 5, 0.125).half()
+    pos = _rand((40, 32), 6)
+    got = K.gemm(a.to(cuda), w.to(cuda), res=pos.to(cuda), res_rows=40, out_dtype=torch.float32).cpu()
+    ref = a.float() @ w.float().t() + pos.repeat(3, 1)
+    assert float((got - ref).abs().max()) < 2e-4
+    # im2col with normalisation LUT, canvas padding and conv padding
+    img = np.random.default_rng(7).integers(0, 256, (2, 20, 28, 3), dtype=np.uint8)
+    lut = _rand((3, 256), 8)
+    cols = K.im2col_u8(torch.from_numpy(img).to(cuda), lut.to(cuda), 32, 32, 7, 7, 4, 3, 152).cpu()
+    canvas = torch.zeros((2, 3, 32, 32))
+    norm = torch.stack([lut[c][torch.from_numpy(img[..., c].astype(np.int64))] for c in range(3)], 1)
+    canvas[:, :, :20, :28] = norm
+    unf = F.unfold(canvas, 7, padding=3, stride=4)  # [2, 3*49, 64] with (c, ky, kx) order
+    unf = unf.view(2, 3, 49, 64).permute(0, 3, 2, 1).reshape(2 * 64, 147)
+    assert torch.equal(cols[:, :147], unf.half()) and float(cols[:, 147:].abs().max()) == 0
+
+
+def test_sam_preprocess_bit_exact(cuda):
+    from lmx import sam, synth, weights
+    from oracle import preprocess as OP
+
+    cfg = sam.HieraConfig(hidden=16, blocks=(1, 1, 1, 1), dims=(16, 32, 64, 128), heads=(1, 2, 4, 8), global_blocks=(),
+                          pos_bkg=(7, 7), fpn_dim=32, image=1024)
+    enc = sam.HieraEncoder(cfg, weights.synth_state_dict(sam.param_spec(cfg), 1), cuda)
+    frames = np.stack([synth.synth_frame(13, 3), synth.synth_frame(13, 77)], 0)
+    img, patches = enc.preprocess(torch.from_numpy(frames).to(cuda))
+    for i in range(2):
+        assert np.array_equal(img[i].cpu().numpy(), OP.sam_resized_u8(frames[i], 1024))
+    pv = torch.from_numpy(OP.sam_pixel_values(frames[1], 1024))[None]
+    unf = F.unfold(pv, 7, padding=3, stride=4).view(1, 3, 49, -1).permute(0, 3, 2, 1).reshape(-1, 147)
+    assert torch.equal(patches[65536:, :147].cpu(), unf.half())
+
+
+def _tiny(image=256):
+    from lmx import sam
+
+    return sam.HieraConfig(hidden=16, blocks=(1, 2, 3, 2), dims=(16, 32, 64, 128), heads=(1, 2, 4, 8), windows=(8, 4, 14, 7),
+                           global_blocks=(4,), pos_bkg=(7, 7), fpn_dim=32, image=image)
+
+
+@pytest.mark.parametrize("image", [256, 320])
+def test_hiera_tiny_matches_oracle(cuda, image):
+    """hd = 16 everywhere; padded windows (grids 16/8 with windows 14/7), Q-pool at three stage changes, a global block."""
+    from lmx import sam, synth, weights
+    from oracle import hiera as OH
+    from oracle import preprocess as OP
+
+    cfg = _tiny(image)
+    sd = weights.synth_state_dict(sam.param_spec(cfg), seed=31)
+    frames = np.stack([synth.synth_frame(14, i) for i in (5, 60)], 0)
+    pv = torch.from_numpy(np.stack([OP.sam_pixel_values(f, image) for f in frames], 0))
+    with torch.no_grad():
+        ref_fpn, ref_stages = OH.encoder_forward(cfg, sd, pv)
+    out = sam.HieraEncoder(cfg, sd, cuda).encode(torch.from_numpy(frames).to(cuda))
+    torch.cuda.synchronize()
+    for s, (got, ref) in enumerate(zip(out["stages"], ref_stages)):
+        rel, cos = _rel(got.cpu(), ref)
+        assert rel < 5e-3 and cos > 1 - 1e-4, f"stage {s}: rel {rel} cos {cos}"
+    for l, (got, ref) in enumerate(zip(out["fpn"], ref_fpn)):
+        rel, cos = _rel(got.float().cpu(), ref.permute(0, 2, 3, 1))
+        assert rel < 5e-3 and cos > 1 - 1e-4, f"fpn {l}: rel {rel} cos {cos}"
+
+
+def test_hiera_b_plus_matches_golden(cuda):
+    """BASELINE cfg#3 architecture (Hiera-B+, 1024^2) from a raw 1080p frame vs the committed fp32 oracle output."""
+    from lmx import sam, synth, weights
+
+    g = np.load(os.path.join(GOLD, "hiera_bplus_w5.npz"))
+    cfg = sam.hiera_b_plus()
+    sd = weights.synth_state_dict(sam.param_spec(cfg), int(g["weight_seed"]))
+    frames = np.stack([synth.synth_frame(int(g["clip_seed"]), int(i)) for i in g["frame_ids"]], 0)
+    out = sam.HieraEncoder(cfg, sd, cuda).encode(torch.from_numpy(frames).to(cuda))
+    torch.cuda.synchronize()
+    emb = out["fpn"][2].float().cpu()[:, ::2, ::2]  # [n,64,64,256] image embedding level (fixture is subsampled)
+    rel, cos = _rel(emb, torch.from_numpy(g["fpn2"]))
+    last = out["stages"][3].cpu()[:, ::2, ::2]
+    rel3, cos3 = _rel(last, torch.from_numpy(g["stage3"]))
+    hi = out["fpn"][0].float().cpu()[:, ::16, ::16]
+    relh, cosh = _rel(hi, torch.from_numpy(g["fpn0_sub"]))
+    print("hiera-b+ vs fp32 oracle: fpn2 rel/cos", rel, cos, "stage3", rel3, cos3, "fpn0", relh, cosh)
+    assert cos > 1 - 1e-4 and rel < 1e-2
+    assert cos3 > 1 - 1e-4 and cosh > 1 - 1e-4

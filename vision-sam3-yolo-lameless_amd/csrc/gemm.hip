@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lmx_gemm_desc p) {
   for (int i = 0; i < FM; ++i) {
     const int m = m0 + wm * (BM / 2) + i * 16 + frow;
     if (m >= p.M) continue;
+    const int mr = p.res_rows > 0 ? m % p.res_rows : m;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + wn * (BN / 2) + j * 16 + fq * 4;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lmx_gemm_desc p) {
       if (OUT_DT == LMX_F32) {
         float* C = reinterpret_cast<float*>(p.C);
         if (p.res) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ldr + n);
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)mr * p.ldr + n);
           v += rr;
         }
         *reinterpret_cast<f32x4*>(C + (int64_t)m * p.ldc + n) = v;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lmx_gemm_desc p) {
         half_t* C = reinterpret_cast<half_t*>(p.C);
         if (p.res) {
           const half4_t rr =
-              *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.res) + (int64_t)m * p.ldr + n);
+              *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.res) + (int64_t)mr * p.ldr + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
         }
@@ -271,6 +272,7 @@ extern "C" int lmx_k_gemm(const lmx_gemm_desc* dp, lmx_stream_t stream) {
   if (d.bias) LMX_REQUIRE(aligned16(d.bias), "lmx_k_gemm: bias must be 16-byte aligned");
   if (d.scale) LMX_REQUIRE(aligned16(d.scale), "lmx_k_gemm: scale must be 16-byte aligned");
   if (d.res) LMX_REQUIRE(d.ldr % 4 == 0 && d.ldr >= d.N, "lmx_k_gemm: bad ldr=%lld", (long long)d.ldr);
+  LMX_REQUIRE(d.res_rows >= 0, "lmx_k_gemm: res_rows");
   if (d.a_mode == 0) {
     LMX_REQUIRE(d.lda >= d.K, "lmx_k_gemm: lda=%lld < K=%d", (long long)d.lda, d.K);
   } else if (d.a_mode == 1) {

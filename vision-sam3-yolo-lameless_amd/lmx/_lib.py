@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("act", C.c_int32), ("out_dtype", C.c_int32), ("a_mode", C.c_int32),
         ("H", C.c_int32), ("W_", C.c_int32), ("Cin", C.c_int32), ("conv_stride", C.c_int32),
-        ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("res_rows", C.c_int32),
     ]
 
 
@@ -59,6 +59,9 @@ SIGNATURES = {
     "lmx_k_upsample2": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
     "lmx_k_detect_decode": (_I, [_VP, _I64, _VP, _I, _I, _I, _I, _F, _I, _I, _VP]),
     "lmx_k_scale_boxes": (_I, [_VP, _I, _F, _F, _F, _F, _F, _VP]),
+    "lmx_k_im2col_u8": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I64, _VP]),
+    "lmx_k_maxpool2": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _I, _VP]),
+    "lmx_k_cast_f32_f16": (_I, [_VP, _I64, _VP, _I64, _I64, _I, _VP]),
 }
 
 _lib = None

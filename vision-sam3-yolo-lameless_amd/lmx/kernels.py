@@ -35,8 +35,9 @@ def _rows(t, what):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
-def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtype=torch.float16):
-    """out[M,N] = res + scale * act(a[M,K] @ w[N,K]^T + bias)   (lmx_k_gemm, a_mode 0)."""
+def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtype=torch.float16, res_rows=0):
+    """out[M,N] = res + scale * act(a[M,K] @ w[N,K]^T + bias)   (lmx_k_gemm, a_mode 0).
+    res_rows > 0: res is a [res_rows, N] table broadcast over the batch (row m uses res[m % res_rows])."""
     _dev(a, w, bias, scale, res, out)
     M, K, lda = _rows(a, "gemm A")
     N, K2, ldw = _rows(w, "gemm W")
@@ -60,12 +61,46 @@ def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtyp
         raise LmxError("gemm: scale must be float32 [N]")
     if res is not None:
         Mr, Nr, ldr = _rows(res, "gemm res")
-        if (Mr, Nr) != (M, N) or res.dtype != out.dtype:
+        if (Mr, Nr) != ((res_rows or M), N) or res.dtype != out.dtype:
             raise LmxError("gemm: residual must match out's shape and dtype")
         d.res, d.ldr = res.data_ptr(), ldr
+    d.res_rows = res_rows
     d.M, d.N, d.K = M, N, K
     d.act, d.out_dtype, d.a_mode = act, _DT[out.dtype], 0
     check(_lib.load().lmx_k_gemm(C.byref(d), _stream()), "lmx_k_gemm")
+    return out
+
+
+def im2col_u8(img, lut, IH, IW, KH, KW, stride, pad, ldo):
+    """u8 [n,rh,rw,3] at the top-left of an IH x IW zero canvas -> f16 [n*OH*OW, ldo] (lmx_k_im2col_u8)."""
+    _dev(img, lut)
+    n, rh, rw, c = img.shape
+    if c != 3 or img.dtype != torch.uint8 or not img.is_contiguous():
+        raise LmxError("im2col_u8: img must be contiguous uint8 [n,h,w,3]")
+    OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
+    out = torch.empty((n * OH * OW, ldo), dtype=torch.float16, device=img.device)
+    check(_lib.load().lmx_k_im2col_u8(_ptr(img), _ptr(lut), _ptr(out), n, rh, rw, IH, IW, KH, KW, stride, pad, ldo,
+                                      _stream()), "lmx_k_im2col_u8")
+    return out
+
+
+def maxpool2(x, out):
+    """2x2/s2 max pool, NHWC f16 or f32, channel slices allowed (lmx_k_maxpool2)."""
+    n, H, W, Cc, ps = _nhwc(x, "maxpool2 x")
+    no, Ho, Wo, Co, pso = _nhwc(out, "maxpool2 out")
+    if (no, Ho, Wo, Co) != (n, H // 2, W // 2, Cc) or x.dtype != out.dtype:
+        raise LmxError("maxpool2: shape/dtype mismatch")
+    check(_lib.load().lmx_k_maxpool2(_ptr(x), ps, _ptr(out), pso, _DT[x.dtype], n, H, W, Cc, _stream()), "lmx_k_maxpool2")
+    return out
+
+
+def cast_f16(x, out=None):
+    _dev(x, out)
+    rows, cols, lds = _rows(x, "cast src")
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float16, device=x.device)
+    check(_lib.load().lmx_k_cast_f32_f16(_ptr(x), lds, _ptr(out), out.stride(0), rows, cols, _stream()),
+          "lmx_k_cast_f32_f16")
     return out
 
 

@@ -1,0 +1,260 @@
+"""SAM image encoder on liblmx — the ``predictor.set_image(image)`` half of services/sam3-pipeline/app/main.py:80.
+
+BASELINE cfg#3 names the SAM2 Hiera-B+ trunk + FPN neck; this module runs it as a launch
+sequence over the C-ABI kernels:
+  pre   : PIL-bilinear ResizeLongestSide(1024) on u8 (lmx_k_pil_resize_*), SamPredictor's (x-mean)/std applied
+          to the frame AS GIVEN (the service hands over BGR: SURVEY Appendix C-2) and the zero pad to 1024^2 are
+          folded into the patch-embed im2col (lmx_k_im2col_u8);
+  trunk : patch-embed GEMM with the windowed position table added in the epilogue (residual broadcast), then 24
+          multi-scale blocks: LN -> qkv GEMM -> [2x2 max Q-pool] -> window / global flash attention addressed IN PLACE
+          on the token grid (no window_partition copies; padded keys take the qkv bias) -> proj GEMM (+residual, or
+          + pooled `proj` shortcut at stage changes) -> LN -> MLP GEMMs (GELU, +residual).  f32 residual stream.
+  neck  : 1x1 lateral GEMMs to 256 channels, nearest-x2 top-down add on levels 2/3 (GEMM residual epilogue).
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import resample
+
+SAM_PIXEL_MEAN = (123.675, 116.28, 103.53)
+SAM_PIXEL_STD = (58.395, 57.12, 57.375)
+
+
+@dataclass
+class HieraConfig:
+    hidden: int = 112
+    blocks: tuple = (2, 3, 16, 3)
+    dims: tuple = (112, 224, 448, 896)
+    heads: tuple = (2, 4, 8, 16)
+    windows: tuple = (8, 4, 14, 7)
+    global_blocks: tuple = (12, 16, 20)
+    pos_bkg: tuple = (14, 14)
+    q_pool_stages: int = 3
+    fpn_dim: int = 256
+    fpn_top_down: tuple = (2, 3)
+    eps: float = 1e-6
+    image: int = 1024
+
+    def block_plan(self):
+        """[(dim_in, dim_out, heads, window, q_stride)] per block (TF sam2 :466-486)."""
+        plan, t = [], 0
+        for s, nb in enumerate(self.blocks):
+            for b in range(nb):
+                first = s > 0 and b == 0
+                dim = self.dims[s - 1] if first else self.dims[s]
+                win = self.windows[s - 1] if first else self.windows[s]
+                if t in self.global_blocks:
+                    win = 0
+                qs = 2 if (0 < s <= self.q_pool_stages and b == 0) else 0
+                plan.append((dim, self.dims[s], self.heads[s], win, qs))
+                t += 1
+        return plan
+
+
+def hiera_b_plus():
+    return HieraConfig()
+
+
+def param_spec(cfg):
+    """Ordered {transformers Sam2VisionModel parameter name: (shape, init kind)}."""
+    s = {}
+    s["backbone.pos_embed"] = ((1, cfg.hidden) + tuple(cfg.pos_bkg), "tok")
+    s["backbone.pos_embed_window"] = ((1, cfg.hidden, cfg.windows[0], cfg.windows[0]), "tok")
+    s["backbone.patch_embed.projection.weight"] = ((cfg.hidden, 3, 7, 7), "w")
+    s["backbone.patch_embed.projection.bias"] = ((cfg.hidden,), "b")
+    for i, (dim, dim_out, heads, win, qs) in enumerate(cfg.block_plan()):
+        p = f"backbone.blocks.{i}."
+        s[p + "layer_norm1.weight"] = ((dim,), "g")
+        s[p + "layer_norm1.bias"] = ((dim,), "b")
+        s[p + "attn.qkv.weight"] = ((3 * dim_out, dim), "w")
+        s[p + "attn.qkv.bias"] = ((3 * dim_out,), "b")
+        s[p + "attn.proj.weight"] = ((dim_out, dim_out), "w")
+        s[p + "attn.proj.bias"] = ((dim_out,), "b")
+        s[p + "layer_norm2.weight"] = ((dim_out,), "g")
+        s[p + "layer_norm2.bias"] = ((dim_out,), "b")
+        s[p + "mlp.proj_in.weight"] = ((4 * dim_out, dim_out), "w")
+        s[p + "mlp.proj_in.bias"] = ((4 * dim_out,), "b")
+        s[p + "mlp.proj_out.weight"] = ((dim_out, 4 * dim_out), "w")
+        s[p + "mlp.proj_out.bias"] = ((dim_out,), "b")
+        if dim != dim_out:
+            s[p + "proj.weight"] = ((dim_out, dim), "w")
+            s[p + "proj.bias"] = ((dim_out,), "b")
+    for j, c in enumerate(reversed(cfg.dims)):
+        s[f"neck.convs.{j}.weight"] = ((cfg.fpn_dim, c, 1, 1), "w")
+        s[f"neck.convs.{j}.bias"] = ((cfg.fpn_dim,), "b")
+    return s
+
+
+def resize_longest_side(h, w, target=1024):
+    """segment_anything ResizeLongestSide.get_preprocess_shape: int(x*scale + 0.5)."""
+    scale = target * 1.0 / max(h, w)
+    return int(h * scale + 0.5), int(w * scale + 0.5)
+
+
+def sam_norm_lut():
+    """lut[c][u] = (f32(u) - mean[c]) / std[c] — Sam.preprocess' `(x - pixel_mean) / pixel_std` on the f32 image."""
+    u = np.arange(256, dtype=np.float32)
+    m = np.array(SAM_PIXEL_MEAN, np.float32)
+    s = np.array(SAM_PIXEL_STD, np.float32)
+    return ((u[None, :] - m[:, None]) / s[:, None]).astype(np.float32)
+
+
+class HieraEncoder:
+    """Device-resident Hiera trunk + FPN.  ``encode(frames)`` -> dict(fpn=[3 NHWC f16 levels, high->low res],
+    stages=[4 f32 stage outputs]).  Token grids are [n, H, W, C] row-major throughout (no partition copies)."""
+
+    def __init__(self, cfg, state_dict, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        dev = self.device
+        sd = state_dict
+
+        def t32(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+        def t16(a):
+            return t32(a).to(torch.float16).contiguous()
+
+        # patch embed: conv [D,3,7,7] -> GEMM [D, (ky,kx,c)] padded to K%8==0
+        w = np.transpose(sd["backbone.patch_embed.projection.weight"], (0, 2, 3, 1)).reshape(cfg.hidden, 147)
+        self.k_pad = 152
+        self.pe_w = t16(np.concatenate([w, np.zeros((cfg.hidden, self.k_pad - 147), np.float32)], 1))
+        self.pe_b = t32(sd["backbone.patch_embed.projection.bias"])
+        # windowed position table for the (fixed) input grid, computed once on the host like _get_pos_embed (:640-646)
+        g = cfg.image // 4
+        pe = torch.nn.functional.interpolate(torch.from_numpy(sd["backbone.pos_embed"]), size=(g, g), mode="bicubic")
+        win = torch.from_numpy(sd["backbone.pos_embed_window"])
+        pe = pe + win.tile([x // y for x, y in zip(pe.shape, win.shape)])
+        self.pos = pe.permute(0, 2, 3, 1).reshape(g * g, cfg.hidden).contiguous().to(dev)
+        self.grid0 = g
+        self.blocks = []
+        for i, (dim, dim_out, heads, win_, qs) in enumerate(cfg.block_plan()):
+            p = f"backbone.blocks.{i}."
+            qkv_b = sd[p + "attn.qkv.bias"]
+            blk = dict(dim=dim, dim_out=dim_out, heads=heads, win=win_, qs=qs,
+                       g1=t32(sd[p + "layer_norm1.weight"]), b1=t32(sd[p + "layer_norm1.bias"]),
+                       wqkv=t16(sd[p + "attn.qkv.weight"]), bqkv=t32(qkv_b),
+                       # what Linear(0) yields for a zero-padded token, rounded like the GEMM output
+                       padkv=t16(qkv_b),
+                       wo=t16(sd[p + "attn.proj.weight"]), bo=t32(sd[p + "attn.proj.bias"]),
+                       g2=t32(sd[p + "layer_norm2.weight"]), b2=t32(sd[p + "layer_norm2.bias"]),
+                       w1=t16(sd[p + "mlp.proj_in.weight"]), bb1=t32(sd[p + "mlp.proj_in.bias"]),
+                       w2=t16(sd[p + "mlp.proj_out.weight"]), bb2=t32(sd[p + "mlp.proj_out.bias"]))
+            if dim != dim_out:
+                blk["wp"], blk["bp"] = t16(sd[p + "proj.weight"]), t32(sd[p + "proj.bias"])
+            self.blocks.append(blk)
+        n = len(cfg.dims) - 1
+        self.neck = [(t16(sd[f"neck.convs.{n - i}.weight"][:, :, 0, 0]), t32(sd[f"neck.convs.{n - i}.bias"])) for i in range(n + 1)]
+        self.lut = t32(sam_norm_lut())
+        self._tabs = {}
+
+    # ---- preprocessing ------------------------------------------------------------------------------------
+    def _tables(self, h, w):
+        key = (h, w)
+        if key not in self._tabs:
+            nh, nw = resize_longest_side(h, w, self.cfg.image)
+            dev = self.device
+
+            def up(tab):
+                b, k, ks = tab
+                return (torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev), ks)
+
+            th = up(resample.coeff_tables(w, nw, resample.BILINEAR)) if nw != w else None
+            tv = up(resample.coeff_tables(h, nh, resample.BILINEAR)) if nh != h else None
+            self._tabs[key] = (nh, nw, th, tv)
+        return self._tabs[key]
+
+    def preprocess(self, frames):
+        """u8 [n,h,w,3] (channel order as handed over) -> (PIL-resized u8 [n,nh,nw,3], patch matrix f16 [n*g*g, 152])."""
+        n, h, w, _ = frames.shape
+        nh, nw, th, tv = self._tables(h, w)
+        img = K.pil_resize(frames, nw, nh, th, tv, swap_rb=False)
+        S = self.cfg.image
+        return img, K.im2col_u8(img, self.lut, S, S, 7, 7, 4, 3, self.k_pad)
+
+    # ---- network ------------------------------------------------------------------------------------------
+    def trunk(self, patches, n):
+        cfg = self.cfg
+        g = self.grid0
+        x = K.gemm(patches, self.pe_w, bias=self.pe_b, res=self.pos, res_rows=g * g, out_dtype=torch.float32)
+        H = W = g
+        stage_ends = set(int(v) for v in np.cumsum(cfg.blocks) - 1)
+        stages = []
+        dev = x.device
+        for i, B in enumerate(self.blocks):
+            dim, D, heads, win, qs = B["dim"], B["dim_out"], B["heads"], B["win"], B["qs"]
+            hd = D // heads
+            rows = n * H * W
+            h = K.layernorm(x, B["g1"], B["b1"], cfg.eps)
+            if dim != D:
+                sc = K.gemm(h, B["wp"], bias=B["bp"], out_dtype=torch.float32)
+                if qs:
+                    pooled = torch.empty((n, H // 2, W // 2, D), dtype=torch.float32, device=dev)
+                    K.maxpool2(sc.view(n, H, W, D), pooled)
+                    sc = pooled.view(-1, D)
+                res = sc
+            else:
+                res = x
+            qkv = K.gemm(h, B["wqkv"], bias=B["bqkv"])
+            q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+            Hq, Wq = H, W
+            if qs:
+                Hq, Wq = H // 2, W // 2
+                qp = torch.empty((n, Hq, Wq, D), dtype=torch.float16, device=dev)
+                K.maxpool2(qkv.view(n, H, W, 3 * D)[..., :D], qp)
+                q = qp.view(-1, D)
+            a = torch.empty((n * Hq * Wq, D), dtype=torch.float16, device=dev)
+            if win > 0:
+                nW = -(-H // win) * -(-W // win)
+                wq = win // 2 if qs else win
+                K.attention(q, k, v, a, n * nW, heads, wq * wq, win * win, hd, hd ** -0.5,
+                            window=dict(Gh=H, Gw=W, ws=win, q_stride=2 if qs else 1),
+                            pad_k=B["padkv"][D:2 * D], pad_v=B["padkv"][2 * D:])
+            else:
+                K.attention(q, k, v, a, n, heads, Hq * Wq, H * W, hd, hd ** -0.5)
+            H, W = Hq, Wq
+            xo = torch.empty((n * H * W, D), dtype=torch.float32, device=dev) if res is not x else x
+            K.gemm(a, B["wo"], bias=B["bo"], res=res, out=xo)
+            x = xo
+            h2 = K.layernorm(x, B["g2"], B["b2"], cfg.eps)
+            u = K.gemm(h2, B["w1"], bias=B["bb1"], act=K.ACT_GELU)
+            K.gemm(u, B["w2"], bias=B["bb2"], res=x, out=x)
+            if i in stage_ends:
+                stages.append(x.view(n, H, W, D))
+                if i != len(self.blocks) - 1 and self.blocks[i + 1]["dim"] == self.blocks[i + 1]["dim_out"]:
+                    x = x.clone()  # the stage output is kept; a same-width next block would update it in place
+        return stages
+
+    def fpn(self, stages):
+        cfg = self.cfg
+        nlev = len(stages) - 1
+        feats, prev = [], None
+        for i in range(nlev, -1, -1):
+            s = stages[i]
+            n, H, W, C = s.shape
+            a = K.cast_f16(s.view(-1, C))
+            w, b = self.neck[i]
+            out = torch.empty((n, H, W, cfg.fpn_dim), dtype=torch.float16, device=s.device)
+            if i not in cfg.fpn_top_down or i == nlev:
+                K.gemm(a, w, bias=b, out=out.view(-1, cfg.fpn_dim))
+            else:
+                up = torch.empty((n, H, W, cfg.fpn_dim), dtype=torch.float16, device=s.device)
+                K.upsample2(prev, up)
+                K.gemm(a, w, bias=b, res=up.view(-1, cfg.fpn_dim), out=out.view(-1, cfg.fpn_dim))
+            prev = out
+            feats.append(out)
+        return feats[-3:][::-1]
+
+    def encode_patches(self, patches, n):
+        stages = self.trunk(patches, n)
+        return dict(fpn=self.fpn(stages), stages=stages)
+
+    def encode(self, frames):
+        img, patches = self.preprocess(frames)
+        out = self.encode_patches(patches, frames.shape[0])
+        out["resized"] = img
+        return out
