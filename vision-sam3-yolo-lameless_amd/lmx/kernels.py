@@ -347,3 +347,51 @@ def scale_boxes(boxes, padx, pady, gain, w, h):
     check(_lib.load().lmx_k_scale_boxes(_ptr(boxes), boxes.numel() // 4, float(padx), float(pady), float(gain), float(w),
                                         float(h), _stream()), "lmx_k_scale_boxes")
     return boxes
+
+
+# ---- optional per-launch timing of the GEMM kernel (bench.py's roofline leg) -------------------------------------
+# When GEMM_TRACE is a list, every gemm/conv launch appends (algorithmic_flops, start_event, end_event); the events
+# are recorded on torch's current stream, i.e. the stream the kernel itself is enqueued on.
+GEMM_TRACE = None
+_raw_gemm_call = None
+
+
+def _install_trace():
+    global _raw_gemm_call
+    if _raw_gemm_call is not None:
+        return
+    lib = _lib.load()
+    _raw_gemm_call = lib.lmx_k_gemm
+
+    def traced(desc_ref, stream):
+        if GEMM_TRACE is None:
+            return _raw_gemm_call(desc_ref, stream)
+        d = desc_ref._obj
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = _raw_gemm_call(desc_ref, stream)
+        e1.record()
+        GEMM_TRACE.append((2.0 * d.M * d.N * d.K, e0, e1))
+        return rc
+
+    class _Proxy:
+        def __getattr__(self, name):
+            return traced if name == "lmx_k_gemm" else getattr(lib, name)
+
+    _lib._lib = _Proxy()
+
+
+def start_gemm_trace():
+    global GEMM_TRACE
+    _install_trace()
+    GEMM_TRACE = []
+
+
+def stop_gemm_trace():
+    """-> (total algorithmic flops, total seconds, launches) over the traced GEMM launches."""
+    global GEMM_TRACE
+    tr, GEMM_TRACE = GEMM_TRACE or [], None
+    torch.cuda.synchronize()
+    flops = sum(f for f, _, _ in tr)
+    secs = sum(a.elapsed_time(b) for _, a, b in tr) * 1e-3
+    return flops, secs, len(tr)

@@ -1,0 +1,36 @@
+"""The fused per-frame path (BASELINE cfg#5): decoded 1080p BGR frames, resident in HBM, go through the three networks
+of services/{yolo,sam3,dinov3}-pipeline on one GPU.  Frames are independent, so a clip is sharded
+across ranks as contiguous blocks and each rank runs this object on its block; lmx.dist reassembles per-clip records."""
+import os
+
+import torch
+
+from . import dino, sam, yolo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
+
+
+class FusedExtractor:
+    def __init__(self, device="cuda", yolo_scale="l", weight_seeds=(7, 5, 3), yolo_bn=None):
+        """Synthetic weights (no checkpoints exist offline): YOLOv8-{scale}, Hiera-B+, DINOv3 ViT-L/16."""
+        from . import weights
+
+        self.device = torch.device(device)
+        ycfg = yolo.YoloConfig(yolo_scale)
+        bn = yolo_bn or os.path.join(GOLDEN, f"yolov8{yolo_scale}_bn_w{weight_seeds[0]}.npz")
+        self.yolo = yolo.YoloDetector(ycfg, yolo.synthetic_state_dict(ycfg, weight_seeds[0], bn if os.path.exists(bn) else None),
+                                      self.device)
+        scfg = sam.hiera_b_plus()
+        self.sam = sam.HieraEncoder(scfg, weights.synth_state_dict(sam.param_spec(scfg), weight_seeds[1]), self.device)
+        dcfg = dino.dinov3_vitl16()
+        self.dino = dino.DinoEmbedder(dcfg, weights.synth_state_dict(dino.param_spec(dcfg), weight_seeds[2]), self.device)
+
+    def step(self, frames, conf=0.5, sam_chunk=16):
+        """frames u8 [n,1080,1920,3] BGR on device -> dict of device tensors for every frame (dense schedule)."""
+        boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf)
+        emb = self.dino.embed_frames(frames)
+        fpn2 = []
+        for i in range(0, frames.shape[0], sam_chunk):  # Hiera activations are ~100 MB/frame: bound the live set
+            out = self.sam.encode(frames[i:i + sam_chunk])
+            fpn2.append(out["fpn"][2])
+        return dict(boxes=boxes, scores=scores, cls=cls, counts=counts, embedding=emb, image_embedding=torch.cat(fpn2, 0))
