@@ -22,7 +22,7 @@ def _close(got, ref, atol, rtol, what):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (201, 1024, 1024), (77, 80, 72), (1000, 336, 112), (513, 64, 2048),
-                                   (4096, 3072, 1024)])
+                                   (4096, 3072, 1024), (777, 200, 152), (1111, 448, 224), (512, 96, 8), (2049, 1792, 448)])
 @pytest.mark.parametrize("out_dtype", [torch.float16, torch.float32])
 def test_gemm_plain(cuda, M, N, K, out_dtype):
     from lmx import kernels as Kk
@@ -36,11 +36,12 @@ def test_gemm_plain(cuda, M, N, K, out_dtype):
     _close(got, ref, what=f"gemm {M}x{N}x{K}", **tol)
 
 
+@pytest.mark.parametrize("M", [300, 1500])  # 300 -> 128x128 register-staged kernel, 1500 -> 256x128 LDS-DMA kernel
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
-def test_gemm_epilogues(cuda, act):
+def test_gemm_epilogues(cuda, act, M):
     from lmx import kernels as Kk
 
-    M, N, K = 300, 256, 192
+    N, K = 256, 192
     a = _rand((M, K), 4).half()
     w = _rand((N, K), 5, K ** -0.5).half()
     b, s = _rand((N,), 6), _rand((N,), 7)

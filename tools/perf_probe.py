@@ -30,13 +30,27 @@ def main():
     dev = torch.device("cuda:0")
     which = sys.argv[1:] or ["gemm", "dino"]
     if "gemm" in which:
-        for (M, N, K_) in [(51456, 3072, 1024), (51456, 1024, 1024), (51456, 4096, 1024), (51456, 1024, 4096),
-                           (8192, 8192, 8192), (4096, 4096, 4096)]:
+        tot = 0.0
+        # (M, N, K, act, f32-out-with-residual): DINOv3-L b=32 shapes, Hiera-B+ b=16 shapes, two square references
+        for (M, N, K_, act, f32) in [(6432, 3072, 1024, 0, 0), (6432, 1024, 1024, 0, 1), (6432, 4096, 1024, 2, 0),
+                                     (6432, 1024, 4096, 0, 1), (65536, 1792, 448, 2, 0), (65536, 448, 1792, 0, 1),
+                                     (65536, 1344, 448, 0, 0), (65536, 448, 448, 0, 1), (1048576, 448, 112, 2, 0),
+                                     (1048576, 112, 448, 0, 1), (1048576, 336, 112, 0, 0), (262144, 896, 224, 2, 0),
+                                     (262144, 224, 896, 0, 1), (16384, 3584, 896, 2, 0), (16384, 896, 3584, 0, 1),
+                                     (8192, 8192, 8192, 0, 0), (4096, 4096, 4096, 0, 0)]:
             a = torch.randn((M, K_), device=dev).half()
-            w = torch.randn((N, K_), device=dev).half()
-            out = torch.empty((M, N), device=dev, dtype=torch.float16)
-            ms = timeit(lambda: K.gemm(a, w, out=out))
-            print(f"gemm {M}x{N}x{K_}: {ms:.3f} ms  {2 * M * N * K_ / ms / 1e9:.1f} TFLOP/s", flush=True)
+            w = (torch.randn((N, K_), device=dev) * K_ ** -0.5).half()
+            b = torch.randn((N,), device=dev)
+            if f32:
+                out = torch.randn((M, N), device=dev, dtype=torch.float32)
+                ms = timeit(lambda: K.gemm(a, w, bias=b, act=act, res=out, out=out), iters=10)
+            else:
+                out = torch.empty((M, N), device=dev, dtype=torch.float16)
+                ms = timeit(lambda: K.gemm(a, w, bias=b, act=act, out=out), iters=10)
+            tot += ms if M != 8192 and M != 4096 else 0
+            print(f"gemm {M}x{N}x{K_} act{act} {'f32+res' if f32 else 'f16'}: {ms:.3f} ms  {2 * M * N * K_ / ms / 1e9:.1f} TFLOP/s",
+                  flush=True)
+        print(f"model-shape total {tot:.3f} ms", flush=True)
     if "attn" in which or "dino" in which:
         B, H, T, hd = 256, 16, 201, 64
         qkv = torch.randn((B * T, 3 * H * hd), device=dev).half()

@@ -21,6 +21,7 @@
 //   * blockIdx -> tile map is XCD-aware (bijective chunking, guide T1): the blocks that land on one XCD walk
 //     consecutive n-tiles of the same m-panel so the A panel and W stay in that XCD's L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -255,6 +256,17 @@ int dispatch_tile(const lmx_gemm_desc& d, hipStream_t st) {
 
 }  // namespace
 
+int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st);  // gemm2.hip
+
+static bool force_v1() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LMX_GEMM_V1");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 extern "C" int lmx_k_gemm(const lmx_gemm_desc* dp, lmx_stream_t stream) {
   LMX_REQUIRE(dp != nullptr, "lmx_k_gemm: null descriptor");
   const lmx_gemm_desc& d = *dp;
@@ -289,6 +301,8 @@ extern "C" int lmx_k_gemm(const lmx_gemm_desc* dp, lmx_stream_t stream) {
     LMX_REQUIRE(false, "lmx_k_gemm: bad a_mode %d", d.a_mode);
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // large dense problems take the LDS-DMA 256x128 kernel (gemm2.hip); small / narrow ones and the conv generator stay here
+  if (d.a_mode == 0 && d.M >= 512 && d.N >= 96 && !force_v1()) return lmx_gemm2_launch(d, st);
   if (d.a_mode == 0) {
     return d.out_dtype == LMX_F16 ? dispatch_tile<0, LMX_F16>(d, st) : dispatch_tile<0, LMX_F32>(d, st);
   }

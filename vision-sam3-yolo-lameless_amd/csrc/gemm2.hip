@@ -1,0 +1,259 @@
+// gemm2.hip — the second-generation dense GEMM (a_mode 0): 256(m) x 128(n) x 64 block tile, LDS-DMA staging.
+//
+// Why a second kernel: in gemm.hip every staged byte crosses the register file (global_load -> VGPR -> ds_write_b128);
+// on gfx950 ds_write_b128 moves only ~79 B/clk/CU (MI355X_MICROARCH.md §LDS), so a 128x128x64 k-tile pays ~415 LDS-write
+// cycles + ~256 LDS-read cycles against 512 MFMA cycles: the kernel is LDS-bound near 800 TFLOP/s.  Here
+//   * staging is `buffer_load_dwordx4 ... lds` (LDS-DMA): no VGPR round trip, no ds_write; the buffer descriptor's range
+//     check supplies the zero fill for rows >= M / >= N, a per-lane predicate supplies it for the K tail;
+//   * the LDS image keeps the (chunk ^ row&7) swizzle of gemm.hip; because an LDS-DMA wave-instruction writes 64 x 16 B
+//     LINEARLY, the swizzle is applied to the per-lane SOURCE address instead (guide §5.4 rule 21): lane L of the
+//     instruction that fills rows 8j..8j+7 loads logical chunk (L&7)^(L>>3) of row 8j+(L>>3);
+//   * 3-slot LDS ring (3 x 48 KB = 144 KB of the 160 KB), two k-tiles in flight, ONE raw s_barrier per k-tile with a
+//     counted s_waitcnt vmcnt (never 0 inside the loop; guide §5 "Pipelining across barriers");
+//   * 8 waves (two per SIMD) as 4(m) x 2(n), each owning 64 x 64 = 4 x 4 MFMA 16x16x32 fragments: while one wave of a
+//     SIMD waits on its counted vmcnt, issues its 6 LDS-DMAs or reads fragments, its partner keeps the matrix pipe busy
+//     (a 4-wave / one-per-SIMD variant of this kernel measured 949 TFLOP/s at 8192^3: DMA issue and fragment reads of a
+//     lone wave cannot hide behind its own MFMAs).  Per k-tile the CU reads 128 KB of fragments (512 LDS cycles) against
+//     1024 MFMA cycles per SIMD.
+#include "common.h"
+#include <stdlib.h>
+
+// (no anonymous namespace here: hipcc does not emit the host stub of an internal-linkage kernel template that is only
+// instantiated from another template — the library then fails to load with an undefined symbol)
+namespace lmx_gemm2 {
+
+constexpr int BN = 128;
+
+// Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7): rcp + exp + 6 fma instead of libm's branchy erff in the epilogue.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+  const float r = fmaf(-p, e, 1.0f);
+  return copysignf(r, x);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == LMX_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.44269504088896340736f));
+  if (act == LMX_ACT_GELU) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+  if (act == LMX_ACT_RELU) return fmaxf(v, 0.0f);
+  return v;
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// One LDS-DMA wave-instruction (buffer_load_dwordx4 ... lds): lane i's 16 bytes land at dst + 16*i.  Kept in a
+// NON-template function: inside a kernel template with dependent arguments the amdgcn builtin makes the HOST pass drop
+// the kernel's instantiation without a diagnostic (the .so then fails to load with an undefined __device_stub__).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst_lds, unsigned voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst_lds, 16, voffset, soffset, 0, 0);
+}
+
+// counted wait with a literal immediate per instantiation (an "n"-constrained template-dependent asm operand makes
+// hipcc drop the HOST stub of the enclosing kernel template without a diagnostic)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N == 0 || N == 3 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal for this count");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+// BM x 128 x BK tile, NSTAGE-slot LDS ring, (BM/64) x 2 waves of 64 x 64 outputs.
+template <int OUT_DT, int BM, int BK, int NSTAGE, int MINW>
+__global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
+  constexpr int NWAVE = BM / 32;
+  constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+  constexpr int A_INSTR = BM * BK * 2 / 1024 / NWAVE;  // LDS-DMA wave-instructions (1 KB each) per wave per k-tile
+  constexpr int W_INSTR = BN * BK * 2 / 1024 / NWAVE;
+  constexpr int ROWS_PER_INSTR = 1024 / (BK * 2);       // 8 (BK=64) or 16 (BK=32)
+  constexpr int CHUNKS = BK / 8;                        // 16-byte chunks per row: 8 or 4
+  constexpr int LA = NSTAGE - 1;                        // k-tiles issued ahead
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % (BM / 64), wn = wave / (BM / 64);  // (BM/64)(m) x 2(n) waves, 64 x 64 outputs each
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int NT = (p.N + BN - 1) / BN;
+  const int mt = swz / NT, nt = swz - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // buffer descriptors over this block's row panels: the hardware range check returns 0 beyond the last valid byte
+  const char* Ab = reinterpret_cast<const char*>(p.A) + (int64_t)m0 * p.lda * 2;
+  const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.K * 2;
+  int64_t a_bytes = ((int64_t)(p.M - m0 - 1) * p.lda + p.K) * 2;
+  int64_t w_bytes = (int64_t)(p.N - n0) * p.K * 2;
+  if (a_bytes > 0x7FFFFFF0ll) a_bytes = 0x7FFFFFF0ll;
+  if (w_bytes > 0x7FFFFFF0ll) w_bytes = 0x7FFFFFF0ll;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ab), 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, (int)w_bytes, 0x00020000);
+
+  // swizzle: physical 16-B slot = logical chunk ^ sw(row).  BK=64 (128-B rows, 2 per bank row): sw = row & 7.
+  // BK=32 (64-B rows, 4 per bank row): sw = (-(row >> 2)) & 3.  Either makes each 16-lane ds_read_b128 group hit 16
+  // distinct slots of the 256-B bank row.  An LDS-DMA instruction writes its 64 lanes linearly, so the SOURCE is permuted.
+  const int lrow = lane / CHUNKS;
+  const int lsw = (BK == 64) ? (lrow & 7) : ((-(lrow >> 2)) & 3);
+  const int lchunk = (lane % CHUNKS) ^ lsw;
+  unsigned a_off[A_INSTR], w_off[W_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j)
+    a_off[j] = (unsigned)(((wave * A_INSTR + j) * ROWS_PER_INSTR + lrow) * (int)p.lda * 2 + lchunk * 16);
+#pragma unroll
+  for (int j = 0; j < W_INSTR; ++j)
+    w_off[j] = (unsigned)(((wave * W_INSTR + j) * ROWS_PER_INSTR + lrow) * p.K * 2 + lchunk * 16);
+  const unsigned OOB = 0x80000000u;
+  const int nk = (p.K + BK - 1) / BK;
+  const bool k_tail_lane = (nk - 1) * BK + lchunk * 8 >= p.K;  // this lane's chunk is past K in the last k-tile
+
+  auto issue = [&](int kt, int slot) {
+    char* st = smem + slot * STAGE_BYTES;
+    const bool kill = (kt == nk - 1) && k_tail_lane;
+    const int soff = kt * (BK * 2);
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      char* dst = st + (wave * A_INSTR + j) * 1024;
+      lds_dma16(a_rs, dst, kill ? OOB : a_off[j], soff);
+    }
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) {
+      char* dst = st + BM * BK * 2 + (wave * W_INSTR + j) * 1024;
+      lds_dma16(w_rs, dst, kill ? OOB : w_off[j], soff);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int t = 0; t < LA; ++t)
+    if (t < nk) issue(t, t);
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int fsw = (BK == 64) ? (frow & 7) : ((-(frow >> 2)) & 3);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once only the LDS-DMAs of the (at most LA-1) younger tiles are outstanding
+    constexpr int PT = A_INSTR + W_INSTR;
+    const int left = nk - 1 - kt;
+    const int younger = left < LA - 1 ? left : LA - 1;
+    if (younger >= 2)
+      wait_vmcnt<2 * PT>();
+    else if (younger == 1)
+      wait_vmcnt<PT>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + LA < nk) issue(kt + LA, (kt + LA) % NSTAGE);
+    const char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
+    const half_t* as = reinterpret_cast<const half_t*>(st) + (wm * 64 + frow) * BK;
+    const half_t* ws = reinterpret_cast<const half_t*>(st + BM * BK * 2) + (wn * 64 + frow) * BK;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int coff = (((ks << 2) + fq) ^ fsw) << 3;
+      half8_t af[4], wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const half8_t*>(ws + j * 16 * BK + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const half8_t*>(as + i * 16 * BK + coff);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  // epilogue: lane owns row m (lane&15), 4 consecutive channels n (lane>>4)*4 per fragment
+  const int act = p.act;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + frow;
+    if (m >= p.M) continue;
+    const int mr = p.res_rows > 0 ? m % p.res_rows : m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (act != LMX_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
+      }
+      if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + n);
+      if (OUT_DT == LMX_F32) {
+        if (p.res) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)mr * p.ldr + n);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = v;
+      } else {
+        if (p.res) {
+          const half4_t rr = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.res) + (int64_t)mr * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+        }
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+        *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+template <int BM, int BK, int NSTAGE, int MINW>
+int launch2(const lmx_gemm_desc& d, hipStream_t st) {
+  const int MT = (d.M + BM - 1) / BM, NT = (d.N + BN - 1) / BN;
+  const size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F16, BM, BK, NSTAGE, MINW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F32, BM, BK, NSTAGE, MINW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  if (d.out_dtype == LMX_F16)
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BK, NSTAGE, MINW>), dim3(MT * NT), dim3(BM * 2), smem, st, d);
+  else
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BK, NSTAGE, MINW>), dim3(MT * NT), dim3(BM * 2), smem, st, d);
+  return lmx_launch_check("gemm2_kernel");
+}
+
+}  // namespace lmx_gemm2
+using namespace lmx_gemm2;
+
+// called from lmx_k_gemm (gemm.hip) after validation, for a_mode 0.  LMX_GEMM2_VARIANT picks a tiling for experiments:
+//   A: 256x128x64, 3 slots (144 KB), 8 waves, 1 block/CU      B: 128x128x64, 2 slots (64 KB), 4 waves, 2 blocks/CU
+//   C: 256x128x32, 3 slots (72 KB), 8 waves, 2 blocks/CU      D: 256x128x32, 2 slots (48 KB), 8 waves, 3 blocks/CU
+int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
+  static int variant = -1;
+  if (variant < 0) {
+    const char* e = getenv("LMX_GEMM2_VARIANT");
+    variant = e ? e[0] : 0;
+  }
+  switch (variant) {
+    case 'A': return launch2<256, 64, 3, 2>(d, st);
+    case 'B': return launch2<128, 64, 2, 2>(d, st);
+    case 'C': return launch2<256, 32, 3, 4>(d, st);
+    case 'D': return launch2<256, 32, 2, 4>(d, st);
+    default:
+      // measured on the model shapes (profiles/r01_gemm_variants.txt): with K <= ~2k the per-tile prologue/epilogue
+      // dominates and two co-resident blocks (C) hide it; long-K problems prefer the deeper 64-wide ring (A)
+      return d.K >= 3072 ? launch2<256, 64, 3, 2>(d, st) : launch2<256, 32, 3, 4>(d, st);
+  }
+}

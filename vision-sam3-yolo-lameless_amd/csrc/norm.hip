@@ -6,6 +6,48 @@ namespace {
 
 // One 64-lane wave per row; the row is held in registers (<= 16 float4 per lane) between the mean pass and the
 // variance pass, so HBM is read exactly once.  Matches torch.nn.LayerNorm (biased variance, eps inside rsqrt).
+// Narrow rows (D <= 128, Hiera stage 1): a 64-lane wave would leave more than half its lanes idle, so a row is given to
+// a 32-lane half-wave (LPR = 32) and the reductions stop at xor 16.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int IN_DT, int OUT_DT>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const void* __restrict__ xv, int64_t ldx,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, void* __restrict__ yv,
+                                                               int64_t ldy, int rows, int D, float eps) {
+  const int l = threadIdx.x & 31;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool live = row < rows;
+  const int c = l * 4;
+  const bool ok = live && c < D;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    if (IN_DT == LMX_F32) {
+      v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(xv) + (int64_t)row * ldx + c);
+    } else {
+      const half4_t hv = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(xv) + (int64_t)row * ldx + c);
+      v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+    }
+  }
+  const float mean = group_sum<32>((v[0] + v[1]) + (v[2] + v[3])) / (float)D;
+  const f32x4 dl = ok ? v - mean : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float var = group_sum<32>((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3])) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (!ok) return;
+  const f32x4 o = dl * rstd * *reinterpret_cast<const f32x4*>(gamma + c) + *reinterpret_cast<const f32x4*>(beta + c);
+  if (OUT_DT == LMX_F32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(yv) + (int64_t)row * ldy + c) = o;
+  } else {
+    half4_t h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+    *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(yv) + (int64_t)row * ldy + c) = h;
+  }
+}
+
 template <int IN_DT, int OUT_DT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ xv, int64_t ldx,
                                                         const float* __restrict__ gamma,
@@ -154,6 +196,20 @@ extern "C" int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const f
   LMX_REQUIRE((((uintptr_t)x) & (in_dtype == LMX_F32 ? 15 : 7)) == 0, "lmx_k_layernorm: x alignment");
   LMX_REQUIRE((((uintptr_t)y) & (out_dtype == LMX_F32 ? 15 : 7)) == 0, "lmx_k_layernorm: y alignment");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (D <= 128) {
+    dim3 g8((rows + 7) / 8), b256(256);
+    if (in_dtype == LMX_F32 && out_dtype == LMX_F16)
+      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F32, LMX_F16>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    else if (in_dtype == LMX_F32 && out_dtype == LMX_F32)
+      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F32, LMX_F32>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    else if (in_dtype == LMX_F16 && out_dtype == LMX_F16)
+      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F16, LMX_F16>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    else if (in_dtype == LMX_F16 && out_dtype == LMX_F32)
+      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F16, LMX_F32>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    else
+      LMX_REQUIRE(false, "lmx_k_layernorm: bad dtypes %d -> %d", in_dtype, out_dtype);
+    return lmx_launch_check("layernorm_narrow_kernel");
+  }
   dim3 grid((rows + 3) / 4), block(256);
   if (in_dtype == LMX_F32 && out_dtype == LMX_F16)
     hipLaunchKernelGGL((layernorm_kernel<LMX_F32, LMX_F16>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);

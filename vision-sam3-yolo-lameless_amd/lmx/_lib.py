@@ -76,7 +76,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  lmx has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=os.RTLD_NOW)  # resolve every symbol now: a broken build fails here, not mid-run
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
