@@ -80,7 +80,8 @@ int lmx_k_gemm(const lmx_gemm_desc* d, lmx_stream_t stream);
  * variance (mean first) in f32.  D%4==0, D<=4096.
  */
 int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const float* gamma, const float* beta,
-                    void* y, int out_dtype, int64_t ldy, int rows, int D, float eps, lmx_stream_t stream);
+                    void* y, int out_dtype, int64_t ldy, int rows, int D, float eps, int act, lmx_stream_t stream);
+/* (act = LMX_ACT_NONE or LMX_ACT_GELU applied after the affine: the SAM decoder's LayerNorm2d -> GELU, TF sam :523) */
 
 /* ---- K13/K14: attention (flash-style, online softmax in f32, S and PV on MFMA) ----------------------
  * O[b,t,h,:] = softmax_j( scale * Q[b,t,h,:] . K[b,j,h,:] ) V[b,j,h,:]
@@ -198,6 +199,26 @@ int lmx_k_maxpool2(const void* src, int64_t lds, void* dst, int64_t ldd, int dty
 /* f32 -> f16 row-wise convert (stage outputs of the f32 residual stream feeding the FPN 1x1 convs). */
 int lmx_k_cast_f32_f16(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int cols,
                        lmx_stream_t stream);
+
+/* ---- SAM mask decoder glue (TF:models/sam/modeling_sam.py:432-543; K18/K19) --------------------------------------- */
+/* out[r][:] = a[r][:] + b[r % b_rows][:]  (a, b f32; out f32 or f16): queries + point embeddings, keys + image PE,
+ * image embedding + no-mask dense embedding. */
+int lmx_k_add_bcast(const void* a, int a_dtype, int64_t lda, const float* b, int64_t ldb, int b_rows, void* out,
+                    int out_dtype, int64_t ldo, int64_t rows, int D, lmx_stream_t stream);
+/* SamPromptEncoder._embed_boxes (TF sam :650-659) on device: boxes f32 [n][4] xyxy in FRAME pixels are scaled to the
+ * resized image (ResizeLongestSide.apply_boxes: x*nw/w, y*nh/h in double), +0.5, /S, 2c-1, @gauss [2][F], *2pi,
+ * [sin|cos] -> sparse f32 [n][2][2F], + corner[0|1] (the point_embed[2|3] rows, f32 [2][2F]). */
+int lmx_k_prompt_box(const float* boxes, int64_t ldb, float* sparse, int n, double sx, double sy, float S,
+                     const float* gauss, const float* corner, int F, lmx_stream_t stream);
+/* masks[:,0] = hyper_in[:,0] @ upscaled: up f16 [n][G*G][4][4][C] (the two ConvTranspose2d(k2,s2) outputs kept in
+ * nested quadrant order: pixel (y,x) of the GxG grid, then (dy1,dx1), then (dy2,dx2)), hyper f32 [n][C] ->
+ * logits f32 [n][4G][4G] in spatial order (Y = 4y + 2dy1 + dy2, X = 4x + 2dx1 + dx2).  C%8==0, C<=64. */
+int lmx_k_hyper_mask(const void* up, const float* hyper, float* logits, int n, int G, int C, lmx_stream_t stream);
+/* Sam.postprocess_masks + threshold + mask statistics: logits f32 [n][L][L] -> bilinear (align_corners=False) to
+ * TxT, crop [:nh,:nw], bilinear to h x w, > 0  => mask u8 [n][h][w] (0/1);  stats int64 [n][8] =
+ * (area, sum_x, sum_y, min_x, min_y, max_x, max_y, 0) over mask pixels (min/max = +-big when empty). */
+int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh, int nw, int h, int w, uint8_t* mask,
+                    int64_t* stats, lmx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -121,3 +121,53 @@ def test_hiera_b_plus_matches_golden(cuda):
     print("hiera-b+ vs fp32 oracle: fpn2 rel/cos", rel, cos, "stage3", rel3, cos3, "fpn0", relh, cosh)
     assert cos > 1 - 1e-4 and rel < 1e-2
     assert cos3 > 1 - 1e-4 and cosh > 1 - 1e-4
+
+
+def test_mask_decoder_matches_oracle(cuda):
+    """Prompt encoder + two-way decoder + upscaler + post-processing vs the fp32 oracle on the same embeddings/boxes.
+    Bar (BASELINE.json north_star): mask IoU >= 0.999."""
+    from lmx import kernels as K
+    from lmx import sam_decoder
+    from oracle import sam_decoder as OD
+
+    sd = sam_decoder.synthetic_state_dict(41)
+    rng = np.random.default_rng(3)
+    n = 3
+    # smooth embeddings (low-pass) so that the logits form blobs, not salt-and-pepper
+    base = torch.from_numpy(rng.standard_normal((n, 256, 8, 8)).astype(np.float32))
+    emb = F.interpolate(base, size=(64, 64), mode="bilinear", align_corners=False) * 2.0
+    emb = (emb + 0.1 * torch.from_numpy(rng.standard_normal(emb.shape).astype(np.float32))).half().float()
+    boxes = np.array([[300.0, 150.0, 1200.0, 900.0], [10.0, 20.0, 1900.0, 1000.0], [800.5, 400.25, 1000.0, 700.0]], np.float32)
+    hw, rhw = (1080, 1920), (576, 1024)
+    with torch.no_grad():
+        sp = OD.prompt_encode_box(sd, torch.from_numpy(OD.scale_box(boxes, hw, rhw)))
+        low_ref, iou_ref = OD.mask_decode(sd, emb, sp)
+        mask_ref = OD.postprocess(low_ref, rhw, hw)
+    dec = sam_decoder.MaskDecoder(sd, cuda)
+    d_emb = emb.permute(0, 2, 3, 1).reshape(n * 4096, 256).contiguous().half().to(cuda)
+    out = dec.predict(d_emb, torch.from_numpy(boxes).to(cuda), hw, rhw)
+    torch.cuda.synchronize()
+    sparse = K.prompt_box(torch.from_numpy(boxes).to(cuda), rhw[1] / hw[1], rhw[0] / hw[0], 1024.0, dec.gauss, dec.corner).cpu()
+    assert float((sparse - sp).abs().max()) < 2e-4
+    low = out["lowres"].cpu()
+    rel = float((low - low_ref).norm() / low_ref.norm())
+    print("decoder lowres rel err", rel, "iou head", out["iou"].cpu().tolist(), iou_ref.tolist())
+    assert rel < 2e-2
+    m = out["mask"].cpu().bool()
+    for i in range(n):
+        inter = float((m[i] & mask_ref[i]).sum())
+        union = float((m[i] | mask_ref[i]).sum())
+        iou = inter / union if union else 1.0
+        frac = float(mask_ref[i].float().mean())
+        print(f"mask {i}: IoU {iou:.6f}, coverage {frac:.3f}")
+        assert 0.02 < frac < 0.98, "degenerate reference mask: the test would not measure anything"
+        assert iou >= 0.999, f"mask {i}: IoU {iou}"
+    # mask_post alone on the oracle's logits: exact same pixels except where |value| ~ 0, and exact statistics
+    mk, st = K.mask_post(low_ref.to(cuda), 1024, rhw[0], rhw[1], hw[0], hw[1])
+    mk, st = mk.cpu().bool(), st.cpu()
+    for i in range(n):
+        diff = int((mk[i] ^ mask_ref[i]).sum())
+        assert diff <= 20, f"mask_post differs from torch interpolate on {diff} pixels"
+        ys, xs = torch.nonzero(mk[i], as_tuple=True)
+        assert st[i, 0] == len(ys) and st[i, 1] == int(xs.sum()) and st[i, 2] == int(ys.sum())
+        assert (st[i, 3], st[i, 4], st[i, 5], st[i, 6]) == (int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max()))

@@ -19,7 +19,7 @@ template <int IN_DT, int OUT_DT>
 __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const void* __restrict__ xv, int64_t ldx,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, void* __restrict__ yv,
-                                                               int64_t ldy, int rows, int D, float eps) {
+                                                               int64_t ldy, int rows, int D, float eps, int act) {
   const int l = threadIdx.x & 31;
   const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
   const bool live = row < rows;
@@ -39,7 +39,11 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const void* __res
   const float var = group_sum<32>((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3])) / (float)D;
   const float rstd = 1.0f / sqrtf(var + eps);
   if (!ok) return;
-  const f32x4 o = dl * rstd * *reinterpret_cast<const f32x4*>(gamma + c) + *reinterpret_cast<const f32x4*>(beta + c);
+  f32x4 o = dl * rstd * *reinterpret_cast<const f32x4*>(gamma + c) + *reinterpret_cast<const f32x4*>(beta + c);
+  if (act == LMX_ACT_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = 0.5f * o[e] * (1.0f + erff(o[e] * 0.70710678118654752440f));
+  }
   if (OUT_DT == LMX_F32) {
     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(yv) + (int64_t)row * ldy + c) = o;
   } else {
@@ -52,7 +56,7 @@ template <int IN_DT, int OUT_DT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ xv, int64_t ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ yv,
-                                                        int64_t ldy, int rows, int D, float eps) {
+                                                        int64_t ldy, int rows, int D, float eps, int act) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -88,7 +92,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     if (c < D) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
       const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
-      const f32x4 o = (v[i] - mean) * rstd * g + b;
+      f32x4 o = (v[i] - mean) * rstd * g + b;
+      if (act == LMX_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = 0.5f * o[e] * (1.0f + erff(o[e] * 0.70710678118654752440f));
+      }
       if (OUT_DT == LMX_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(yv) + (int64_t)row * ldy + c) = o;
       } else {
@@ -188,10 +196,11 @@ inline int grid_for(int64_t total, int block = 256) {
 }  // namespace
 
 extern "C" int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const float* gamma, const float* beta,
-                               void* y, int out_dtype, int64_t ldy, int rows, int D, float eps, lmx_stream_t stream) {
+                               void* y, int out_dtype, int64_t ldy, int rows, int D, float eps, int act, lmx_stream_t stream) {
   LMX_REQUIRE(x && y && gamma && beta, "lmx_k_layernorm: null pointer");
   LMX_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, "lmx_k_layernorm: rows=%d D=%d (need D%%4==0, D<=4096)", rows, D);
   LMX_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= D && ldy >= D, "lmx_k_layernorm: strides");
+  LMX_REQUIRE(act == LMX_ACT_NONE || act == LMX_ACT_GELU, "lmx_k_layernorm: act %d", act);
   LMX_REQUIRE(aligned16(gamma) && aligned16(beta), "lmx_k_layernorm: gamma/beta alignment");
   LMX_REQUIRE((((uintptr_t)x) & (in_dtype == LMX_F32 ? 15 : 7)) == 0, "lmx_k_layernorm: x alignment");
   LMX_REQUIRE((((uintptr_t)y) & (out_dtype == LMX_F32 ? 15 : 7)) == 0, "lmx_k_layernorm: y alignment");
@@ -199,26 +208,26 @@ extern "C" int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const f
   if (D <= 128) {
     dim3 g8((rows + 7) / 8), b256(256);
     if (in_dtype == LMX_F32 && out_dtype == LMX_F16)
-      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F32, LMX_F16>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F32, LMX_F16>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
     else if (in_dtype == LMX_F32 && out_dtype == LMX_F32)
-      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F32, LMX_F32>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F32, LMX_F32>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
     else if (in_dtype == LMX_F16 && out_dtype == LMX_F16)
-      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F16, LMX_F16>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F16, LMX_F16>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
     else if (in_dtype == LMX_F16 && out_dtype == LMX_F32)
-      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F16, LMX_F32>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+      hipLaunchKernelGGL((layernorm_narrow_kernel<LMX_F16, LMX_F32>), g8, b256, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
     else
       LMX_REQUIRE(false, "lmx_k_layernorm: bad dtypes %d -> %d", in_dtype, out_dtype);
     return lmx_launch_check("layernorm_narrow_kernel");
   }
   dim3 grid((rows + 3) / 4), block(256);
   if (in_dtype == LMX_F32 && out_dtype == LMX_F16)
-    hipLaunchKernelGGL((layernorm_kernel<LMX_F32, LMX_F16>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    hipLaunchKernelGGL((layernorm_kernel<LMX_F32, LMX_F16>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
   else if (in_dtype == LMX_F32 && out_dtype == LMX_F32)
-    hipLaunchKernelGGL((layernorm_kernel<LMX_F32, LMX_F32>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    hipLaunchKernelGGL((layernorm_kernel<LMX_F32, LMX_F32>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
   else if (in_dtype == LMX_F16 && out_dtype == LMX_F16)
-    hipLaunchKernelGGL((layernorm_kernel<LMX_F16, LMX_F16>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    hipLaunchKernelGGL((layernorm_kernel<LMX_F16, LMX_F16>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
   else if (in_dtype == LMX_F16 && out_dtype == LMX_F32)
-    hipLaunchKernelGGL((layernorm_kernel<LMX_F16, LMX_F32>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    hipLaunchKernelGGL((layernorm_kernel<LMX_F16, LMX_F32>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
   else
     LMX_REQUIRE(false, "lmx_k_layernorm: bad dtypes %d -> %d", in_dtype, out_dtype);
   return lmx_launch_check("layernorm_kernel");

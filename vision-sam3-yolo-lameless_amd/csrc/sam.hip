@@ -84,6 +84,157 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
   }
 }
 
+
+// out[r] = a[r] + b[r % b_rows]
+template <int IN_DT, int OUT_DT>
+__global__ __launch_bounds__(256) void add_bcast_kernel(const void* __restrict__ av, int64_t lda, const float* __restrict__ b,
+                                                        int64_t ldb, int b_rows, void* __restrict__ out, int64_t ldo, int64_t rows,
+                                                        int D) {
+  const int cc = D / 4;
+  const int64_t total = rows * cc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cc) * 4;
+    const int64_t r = i / cc;
+    f32x4 v;
+    if (IN_DT == LMX_F32) {
+      v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(av) + r * lda + c);
+    } else {
+      const half4_t hv = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(av) + r * lda + c);
+      v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+    }
+    v += *reinterpret_cast<const f32x4*>(b + (r % b_rows) * ldb + c);
+    if (OUT_DT == LMX_F32) {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + r * ldo + c) = v;
+    } else {
+      half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(out) + r * ldo + c) = h;
+    }
+  }
+}
+
+// thread = one of the 16 sub-pixels of one grid cell: dot(up[..][C], hyper[n][C]) written at its spatial position.
+__global__ __launch_bounds__(256) void hyper_mask_kernel(const half_t* __restrict__ up, const float* __restrict__ hyper,
+                                                         float* __restrict__ logits, int n, int G, int C) {
+  const int64_t total = (int64_t)n * G * G * 16;
+  const int S = 4 * G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q2 = (int)(i & 3), q1 = (int)((i >> 2) & 3);
+    const int64_t cell = i >> 4;
+    const int x = (int)(cell % G);
+    const int64_t r = cell / G;
+    const int y = (int)(r % G);
+    const int b = (int)(r / G);
+    const half_t* u = up + i * C;
+    const float* hy = hyper + (int64_t)b * C;
+    float acc = 0.f;
+    for (int c = 0; c < C; c += 8) {
+      const half8_t v = *reinterpret_cast<const half8_t*>(u + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = fmaf((float)v[e], hy[c + e], acc);
+    }
+    const int Y = 4 * y + 2 * (q1 >> 1) + (q2 >> 1), X = 4 * x + 2 * (q1 & 1) + (q2 & 1);
+    logits[((int64_t)b * S + Y) * S + X] = acc;
+  }
+}
+
+// torch upsample_bilinear2d(align_corners=False) source index: scale*(dst+0.5)-0.5 clamped at 0
+__device__ __forceinline__ void bil_idx(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+__device__ __forceinline__ float sample_mid(const float* __restrict__ lg, int L, int T, float sLT, int Y, int X) {
+  // value of the TxT bilinear upsample of the LxL logits at integer position (Y, X)
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bil_idx(sLT, Y, L, y0, y1, ly);
+  bil_idx(sLT, X, L, x0, x1, lx);
+  const float t0 = (1.f - lx) * lg[y0 * L + x0] + lx * lg[y0 * L + x1];
+  const float t1 = (1.f - lx) * lg[y1 * L + x0] + lx * lg[y1 * L + x1];
+  return (1.f - ly) * t0 + ly * t1;
+}
+
+__global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict__ logits, int n, int L, int T, int nh, int nw,
+                                                        int h, int w, uint8_t* __restrict__ mask,
+                                                        unsigned long long* __restrict__ stats) {
+  const int b = blockIdx.y;
+  const float* lg = logits + (int64_t)b * L * L;
+  const float sLT = (float)L / (float)T, sy = (float)nh / (float)h, sx = (float)nw / (float)w;
+  unsigned long long area = 0, sumx = 0, sumy = 0;
+  int minx = 0x7fffffff, miny = 0x7fffffff, maxx = -1, maxy = -1;
+  const int64_t total = (int64_t)h * w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w), y = (int)(i / w);
+    int Y0, Y1, X0, X1;
+    float ly, lx;
+    bil_idx(sy, y, nh, Y0, Y1, ly);
+    bil_idx(sx, x, nw, X0, X1, lx);
+    const float v00 = sample_mid(lg, L, T, sLT, Y0, X0), v01 = sample_mid(lg, L, T, sLT, Y0, X1);
+    const float v10 = sample_mid(lg, L, T, sLT, Y1, X0), v11 = sample_mid(lg, L, T, sLT, Y1, X1);
+    const float t0 = (1.f - lx) * v00 + lx * v01, t1 = (1.f - lx) * v10 + lx * v11;
+    const float v = (1.f - ly) * t0 + ly * t1;
+    const bool on = v > 0.0f;
+    mask[(int64_t)b * total + i] = on ? 1 : 0;
+    if (on) {
+      ++area;
+      sumx += (unsigned)x;
+      sumy += (unsigned)y;
+      minx = x < minx ? x : minx;
+      maxx = x > maxx ? x : maxx;
+      miny = y < miny ? y : miny;
+      maxy = y > maxy ? y : maxy;
+    }
+  }
+  // wave reduction then one atomic per wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    area += __shfl_xor(area, o, 64);
+    sumx += __shfl_xor(sumx, o, 64);
+    sumy += __shfl_xor(sumy, o, 64);
+    const int a1 = __shfl_xor(minx, o, 64), a2 = __shfl_xor(miny, o, 64), a3 = __shfl_xor(maxx, o, 64), a4 = __shfl_xor(maxy, o, 64);
+    minx = a1 < minx ? a1 : minx;
+    miny = a2 < miny ? a2 : miny;
+    maxx = a3 > maxx ? a3 : maxx;
+    maxy = a4 > maxy ? a4 : maxy;
+  }
+  if ((threadIdx.x & 63) == 0 && area) {
+    unsigned long long* st = stats + (int64_t)b * 8;
+    atomicAdd(&st[0], area);
+    atomicAdd(&st[1], sumx);
+    atomicAdd(&st[2], sumy);
+    atomicMin(reinterpret_cast<long long*>(&st[3]), (long long)minx);
+    atomicMin(reinterpret_cast<long long*>(&st[4]), (long long)miny);
+    atomicMax(reinterpret_cast<long long*>(&st[5]), (long long)maxx);
+    atomicMax(reinterpret_cast<long long*>(&st[6]), (long long)maxy);
+  }
+}
+
+__global__ __launch_bounds__(256) void prompt_box_kernel(const float* __restrict__ boxes, int64_t ldb, float* __restrict__ sparse,
+                                                        int n, double sx, double sy, float S, const float* __restrict__ gauss,
+                                                        const float* __restrict__ corner, int F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (frame, corner, j)
+  if (i >= n * 2 * F) return;
+  const int j = i % F, k = (i / F) & 1, b = i / (2 * F);
+  const float* bx = boxes + (int64_t)b * ldb + 2 * k;
+  // apply_boxes in double, then the f32 tensor; + 0.5 (pixel centre), / S, 2c - 1
+  const float px = (float)((double)bx[0] * sx) + 0.5f, py = (float)((double)bx[1] * sy) + 0.5f;
+  const float cx = 2.f * (px / S) - 1.f, cy = 2.f * (py / S) - 1.f;
+  const float ang = 6.283185307179586f * (cx * gauss[j] + cy * gauss[F + j]);
+  float* o = sparse + ((int64_t)b * 2 + k) * 2 * F;
+  o[j] = sinf(ang) + corner[k * 2 * F + j];
+  o[F + j] = cosf(ang) + corner[k * 2 * F + F + j];
+}
+
+__global__ void mask_stats_init_kernel(long long* stats, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 8) return;
+  const int f = i & 7;
+  stats[i] = (f == 3 || f == 4) ? 0x7fffffffll : ((f == 5 || f == 6) ? -1ll : 0ll);
+}
+
 }  // namespace
 
 extern "C" int lmx_k_im2col_u8(const uint8_t* img, const float* lut, void* out, int n, int rh, int rw, int IH, int IW, int KH,
@@ -127,4 +278,55 @@ extern "C" int lmx_k_cast_f32_f16(const float* src, int64_t lds, void* dst, int6
   hipLaunchKernelGGL(cast_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, lds,
                      reinterpret_cast<half_t*>(dst), ldd, rows, cols);
   return lmx_launch_check("cast_kernel");
+}
+
+extern "C" int lmx_k_prompt_box(const float* boxes, int64_t ldb, float* sparse, int n, double sx, double sy, float S,
+                                const float* gauss, const float* corner, int F, lmx_stream_t stream) {
+  LMX_REQUIRE(boxes && sparse && gauss && corner && n > 0 && F > 0 && ldb >= 4 && S > 0.f, "lmx_k_prompt_box: arguments");
+  hipLaunchKernelGGL(prompt_box_kernel, dim3((n * 2 * F + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), boxes, ldb,
+                     sparse, n, sx, sy, S, gauss, corner, F);
+  return lmx_launch_check("prompt_box_kernel");
+}
+
+extern "C" int lmx_k_add_bcast(const void* a, int a_dtype, int64_t lda, const float* b, int64_t ldb, int b_rows, void* out,
+                               int out_dtype, int64_t ldo, int64_t rows, int D, lmx_stream_t stream) {
+  LMX_REQUIRE(a && b && out, "lmx_k_add_bcast: null pointer");
+  LMX_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && b_rows > 0 && lda >= D && ldb >= D && ldo >= D && lda % 4 == 0 && ldb % 4 == 0 &&
+                  ldo % 4 == 0, "lmx_k_add_bcast: shape");
+  LMX_REQUIRE(((((uintptr_t)a) & (a_dtype == LMX_F32 ? 15 : 7)) == 0) && aligned16(b) &&
+                  ((((uintptr_t)out) & (out_dtype == LMX_F32 ? 15 : 7)) == 0), "lmx_k_add_bcast: alignment");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = grid_for(rows * (D / 4));
+  if (a_dtype == LMX_F32 && out_dtype == LMX_F32)
+    hipLaunchKernelGGL((add_bcast_kernel<LMX_F32, LMX_F32>), dim3(g), dim3(256), 0, st, a, lda, b, ldb, b_rows, out, ldo, rows, D);
+  else if (a_dtype == LMX_F32 && out_dtype == LMX_F16)
+    hipLaunchKernelGGL((add_bcast_kernel<LMX_F32, LMX_F16>), dim3(g), dim3(256), 0, st, a, lda, b, ldb, b_rows, out, ldo, rows, D);
+  else if (a_dtype == LMX_F16 && out_dtype == LMX_F32)
+    hipLaunchKernelGGL((add_bcast_kernel<LMX_F16, LMX_F32>), dim3(g), dim3(256), 0, st, a, lda, b, ldb, b_rows, out, ldo, rows, D);
+  else if (a_dtype == LMX_F16 && out_dtype == LMX_F16)
+    hipLaunchKernelGGL((add_bcast_kernel<LMX_F16, LMX_F16>), dim3(g), dim3(256), 0, st, a, lda, b, ldb, b_rows, out, ldo, rows, D);
+  else
+    LMX_REQUIRE(false, "lmx_k_add_bcast: dtypes %d -> %d", a_dtype, out_dtype);
+  return lmx_launch_check("add_bcast_kernel");
+}
+
+extern "C" int lmx_k_hyper_mask(const void* up, const float* hyper, float* logits, int n, int G, int C, lmx_stream_t stream) {
+  LMX_REQUIRE(up && hyper && logits, "lmx_k_hyper_mask: null pointer");
+  LMX_REQUIRE(n > 0 && G > 0 && C > 0 && C % 8 == 0 && C <= 64 && aligned16(up), "lmx_k_hyper_mask: shape");
+  hipLaunchKernelGGL(hyper_mask_kernel, dim3(grid_for((int64_t)n * G * G * 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const half_t*>(up), hyper, logits, n, G, C);
+  return lmx_launch_check("hyper_mask_kernel");
+}
+
+extern "C" int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh, int nw, int h, int w, uint8_t* mask, int64_t* stats,
+                               lmx_stream_t stream) {
+  LMX_REQUIRE(logits && mask && stats, "lmx_k_mask_post: null pointer");
+  LMX_REQUIRE(n > 0 && L > 0 && T >= L && nh > 0 && nw > 0 && nh <= T && nw <= T && h > 0 && w > 0, "lmx_k_mask_post: geometry");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, st, reinterpret_cast<long long*>(stats), n);
+  int gx = (int)(((int64_t)h * w + 255) / 256);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(mask_post_kernel, dim3(gx, n), dim3(256), 0, st, logits, n, L, T, nh, nw, h, w, mask,
+                     reinterpret_cast<unsigned long long*>(stats));
+  return lmx_launch_check("mask_post_kernel");
 }

@@ -43,7 +43,7 @@ SIGNATURES = {
     "lmx_last_error": (C.c_char_p, []),
     "lmx_device_count": (_I, []),
     "lmx_k_gemm": (_I, [C.POINTER(GemmDesc), _VP]),
-    "lmx_k_layernorm": (_I, [_VP, _I, _I64, _VP, _VP, _VP, _I, _I64, _I, _I, _F, _VP]),
+    "lmx_k_layernorm": (_I, [_VP, _I, _I64, _VP, _VP, _VP, _I, _I64, _I, _I, _F, _I, _VP]),
     "lmx_k_attention": (_I, [C.POINTER(AttnDesc), _VP]),
     "lmx_k_rope": (_I, [_VP, _I64, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "lmx_k_pil_resize_h": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP]),
@@ -62,6 +62,10 @@ SIGNATURES = {
     "lmx_k_im2col_u8": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I64, _VP]),
     "lmx_k_maxpool2": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _I, _VP]),
     "lmx_k_cast_f32_f16": (_I, [_VP, _I64, _VP, _I64, _I64, _I, _VP]),
+    "lmx_k_add_bcast": (_I, [_VP, _I, _I64, _VP, _I64, _I, _VP, _I, _I64, _I64, _I, _VP]),
+    "lmx_k_prompt_box": (_I, [_VP, _I64, _VP, _I, _D, _D, _F, _VP, _VP, _I, _VP]),
+    "lmx_k_hyper_mask": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
+    "lmx_k_mask_post": (_I, [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
 }
 
 _lib = None

@@ -163,7 +163,7 @@ def conv1x1(x, w, bias=None, act=ACT_SILU, res=None, out=None, out_dtype=torch.f
     return out
 
 
-def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16):
+def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16, act=ACT_NONE):
     _dev(x, gamma, beta, out)
     rows, D, ldx = _rows(x, "layernorm x")
     if out is None:
@@ -172,7 +172,7 @@ def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16):
     if (r2, D2) != (rows, D):
         raise LmxError("layernorm: out shape mismatch")
     check(_lib.load().lmx_k_layernorm(_ptr(x), _DT[x.dtype], ldx, _ptr(gamma), _ptr(beta), _ptr(out), _DT[out.dtype],
-                                      ldy, rows, D, float(eps), _stream()), "lmx_k_layernorm")
+                                      ldy, rows, D, float(eps), act, _stream()), "lmx_k_layernorm")
     return out
 
 
@@ -347,6 +347,48 @@ def scale_boxes(boxes, padx, pady, gain, w, h):
     check(_lib.load().lmx_k_scale_boxes(_ptr(boxes), boxes.numel() // 4, float(padx), float(pady), float(gain), float(w),
                                         float(h), _stream()), "lmx_k_scale_boxes")
     return boxes
+
+
+def add_bcast(a, b, out=None, out_dtype=torch.float32):
+    """out[r] = a[r] + b[r % b_rows]  (a, b float32 2-D; out float32 or float16)."""
+    _dev(a, b, out)
+    rows, D_, lda = _rows(a, "add_bcast a")
+    b_rows, Db, ldb = _rows(b, "add_bcast b")
+    if Db != D_ or a.dtype not in _DT or b.dtype != torch.float32:
+        raise LmxError("add_bcast: a must be float16/float32, b float32, equal width")
+    if out is None:
+        out = torch.empty((rows, D_), dtype=out_dtype, device=a.device)
+    check(_lib.load().lmx_k_add_bcast(_ptr(a), _DT[a.dtype], lda, _ptr(b), ldb, b_rows, _ptr(out), _DT[out.dtype], out.stride(0),
+                                      rows, D_, _stream()), "lmx_k_add_bcast")
+    return out
+
+
+def prompt_box(boxes, sx, sy, S, gauss, corner):
+    """boxes f32 [n,>=4] (row stride allowed) in frame pixels -> sparse f32 [n,2,2F] (lmx_k_prompt_box)."""
+    _dev(boxes, gauss, corner)
+    n = boxes.shape[0]
+    Fq = gauss.shape[1]
+    out = torch.empty((n, 2, 2 * Fq), dtype=torch.float32, device=boxes.device)
+    check(_lib.load().lmx_k_prompt_box(_ptr(boxes), boxes.stride(0), _ptr(out), n, float(sx), float(sy), float(S), _ptr(gauss),
+                                       _ptr(corner), Fq, _stream()), "lmx_k_prompt_box")
+    return out
+
+
+def hyper_mask(up, hyper, n, G, C_):
+    _dev(up, hyper)
+    logits = torch.empty((n, 4 * G, 4 * G), dtype=torch.float32, device=up.device)
+    check(_lib.load().lmx_k_hyper_mask(_ptr(up), _ptr(hyper), _ptr(logits), n, G, C_, _stream()), "lmx_k_hyper_mask")
+    return logits
+
+
+def mask_post(logits, T, nh, nw, h, w):
+    """-> (mask u8 [n,h,w], stats int64 [n,8] = area, sum_x, sum_y, min_x, min_y, max_x, max_y, 0)."""
+    _dev(logits)
+    n, L, _ = logits.shape
+    mask = torch.empty((n, h, w), dtype=torch.uint8, device=logits.device)
+    stats = torch.empty((n, 8), dtype=torch.int64, device=logits.device)
+    check(_lib.load().lmx_k_mask_post(_ptr(logits), n, L, T, nh, nw, h, w, _ptr(mask), _ptr(stats), _stream()), "lmx_k_mask_post")
+    return mask, stats
 
 
 # ---- optional per-launch timing of the GEMM kernel (bench.py's roofline leg) -------------------------------------
