@@ -32,7 +32,9 @@ def cpu_baseline(n_frames, clip_seed):
     from lmx import dino, sam, synth, weights, yolo
     from oracle import hiera as OH
     from oracle import preprocess as OP
+    from oracle import sam_decoder as OD
     from oracle import vit as OV
+    from lmx import sam_decoder
     from oracle import yolo as OY
 
     # the box's CPU share, not the host's core count (a cgroup-limited box oversubscribed 8x runs 100x slower)
@@ -46,17 +48,22 @@ def cpu_baseline(n_frames, clip_seed):
     ysd = yolo.synthetic_state_dict(ycfg, 7, bn)
     ssd = weights.synth_state_dict(sam.param_spec(scfg), 5)
     dsd = weights.synth_state_dict(dino.param_spec(dcfg), 3)
+    msd = sam_decoder.synthetic_state_dict(105)
     frames = [synth.synth_frame(clip_seed, i) for i in range(n_frames)]
     t0 = time.perf_counter()
     with torch.no_grad():
         for j, f in enumerate(frames):
             print(f"[bench] cpu_baseline frame {j + 1}/{n_frames} ({time.perf_counter() - t0:.1f}s)", file=sys.stderr, flush=True)
             OY.predict("l", 80, ysd, f, conf=0.5)
-            OH.encoder_forward(scfg, ssd, torch.from_numpy(OP.sam_pixel_values(f, 1024))[None])
+            fpn, _ = OH.encoder_forward(scfg, ssd, torch.from_numpy(OP.sam_pixel_values(f, 1024))[None])
+            box = np.array([[300.0, 150.0, 1200.0, 900.0]], np.float32)
+            sp = OD.prompt_encode_box(msd, torch.from_numpy(OD.scale_box(box, f.shape[:2], (576, 1024))))
+            low, _ = OD.mask_decode(msd, fpn[2], sp)
+            OD.postprocess(low, (576, 1024), f.shape[:2])
             OV.embed(dcfg, dsd, torch.from_numpy(OP.dino_pixel_values(f))[None])
     dt = time.perf_counter() - t0
     return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_frames} synthetic 1080p frames, YOLOv8-l + Hiera-B+ encoder + DINOv3 ViT-L/16, fp32 PyTorch CPU, batch 1"}
+            "sample": f"{n_frames} synthetic 1080p frames, YOLOv8-l + Hiera-B+ encoder + SAM mask decoder + DINOv3 ViT-L/16, fp32 PyTorch CPU, batch 1"}
 
 
 def main():
@@ -134,9 +141,10 @@ def main():
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "fused dense per-frame path: YOLOv8-l detect (letterbox 384x640, NMS) + SAM2 Hiera-B+ "
-                                   "image encoder + FPN (1024x1024) + DINOv3 ViT-L/16 embed (224x224) on every frame of "
-                                   "synthetic 1080p BGR clips resident in HBM; synthetic weights",
+            "config": {"workload": "fused dense per-frame path: YOLOv8-l detect (letterbox 384x640, NMS, scale_boxes) -> SAM "
+                                   "(Hiera-B+ image encoder + FPN at 1024x1024, box-prompted mask decoder, 1080p mask + stats) "
+                                   "+ DINOv3 ViT-L/16 embed (224x224) on every frame of synthetic 1080p BGR clips resident in "
+                                   "HBM; synthetic weights",
                        "frames_per_gpu_per_step": args.frames, "parallelism": f"frames sharded over {world} GPU(s)",
                        "gflop_per_frame": sum(GFLOP_PER_FRAME.values())},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (lmx_k_gemm: all Linear / 1x1 / 3x3-implicit-GEMM launches)",

@@ -220,6 +220,13 @@ int lmx_k_hyper_mask(const void* up, const float* hyper, float* logits, int n, i
 int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh, int nw, int h, int w, uint8_t* mask,
                     int64_t* stats, lmx_stream_t stream);
 
+/* ---- HOST function (mask pointer is HOST memory) ----------------------------------------------------------------------
+ * extract_segmentation_features (sam3 main.py:102-145) on a 0/1 byte mask [h][w]: out[7] = mask_area, area_ratio,
+ * circularity, aspect_ratio, centroid_x, centroid_y, perimeter.  Restates cv2.findContours(RETR_EXTERNAL,
+ * CHAIN_APPROX_SIMPLE) + contourArea/arcLength/boundingRect of the largest contour + cv2.moments (cv2 absent: parity
+ * unpinned).  Border following is sequential: it stays on the host. */
+int lmx_h_mask_features(const uint8_t* mask_host, int h, int w, double* out_host);
+
 #ifdef __cplusplus
 }
 #endif

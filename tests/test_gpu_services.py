@@ -1,0 +1,86 @@
+"""The three service mirrors over the real HIP backends on a short synthetic 1080p clip: the JSON files and NATS payloads
+of one `video.preprocessed` message, compared with what the fp32 oracle computes for the same sampled frames
+(BASELINE cfg#1/#5 semantics, reference schedule: YOLO/SAM every fps//2-th frame, DINO every fps-th)."""
+import asyncio
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_fused_service_end_to_end(cuda, tmp_path):
+    from lmx import dino, sam, sam_decoder, services, synth, weights, yolo
+    from lmx.services import runtime as R
+    from lmx.services import sam3_pipeline as SP
+    from oracle import hiera as OH
+    from oracle import preprocess as OP
+    from oracle import sam_decoder as OD
+    from oracle import vit as OV
+    from oracle import yolo as OY
+
+    frames = np.stack([synth.synth_frame(3, 40 + 3 * i) for i in range(9)], 0)
+    clip = tmp_path / "clip.npz"
+    R.save_npz_clip(clip, frames, 8.0)  # YOLO/SAM: frames 0,4,8; DINO: frames 0,8
+    # backends: YOLOv8-n, a narrow Hiera (same block structure, 1024^2 input, 256-d FPN) + the SAM decoder, a small DINOv3
+    ycfg = yolo.YoloConfig("n")
+    ysd = yolo.synthetic_state_dict(ycfg, 7, os.path.join(GOLD, "yolov8n_bn_w7.npz"))
+    hcfg = sam.HieraConfig(hidden=16, blocks=(1, 2, 3, 2), dims=(16, 32, 64, 128), heads=(1, 2, 4, 8), global_blocks=(4,),
+                           pos_bkg=(7, 7), fpn_dim=256, image=1024)
+    hsd = weights.synth_state_dict(sam.param_spec(hcfg), 51)
+    msd = sam_decoder.synthetic_state_dict(52)
+    dcfg = dino.DinoConfig(hidden=256, layers=3, heads=4, mlp=1024, registers=4)
+    dsd = weights.synth_state_dict(dino.param_spec(dcfg), 53)
+    bus = R.InProcessBus()
+    cfg = {"nats": {"subjects": dict(R.DEFAULT_SUBJECTS)}, "models": {"yolo": {"confidence_threshold": 0.5}}}
+    y = services.YOLOPipeline(yolo.YoloDetector(ycfg, ysd, cuda), bus, cfg, results_dir=tmp_path / "yolo")
+    seg = SP.HieraSegmenter(sam.HieraEncoder(hcfg, hsd, cuda), sam_decoder.MaskDecoder(msd, cuda))
+    s = services.SAM3Pipeline(seg, bus, cfg, results_dir=tmp_path / "sam3", yolo_results_dir=tmp_path / "yolo")
+    d = services.DINOv3Pipeline(dino.DinoEmbedder(dcfg, dsd, cuda), bus, None, cfg, results_dir=tmp_path / "dino")
+    fused = services.FusedFeatureService(y, s, d)
+    asyncio.run(fused.start())
+    asyncio.run(bus.publish("video.preprocessed", {"video_id": "clip1", "processed_path": str(clip), "filename": "clip1.mp4"}))
+    assert [p[0] for p in bus.published] == ["video.preprocessed", "pipeline.yolo", "pipeline.sam3", "pipeline.dinov3"]
+
+    yj = json.load(open(tmp_path / "yolo" / "clip1_yolo.json"))
+    sj = json.load(open(tmp_path / "sam3" / "clip1_sam3.json"))
+    dj = json.load(open(tmp_path / "dino" / "clip1_dinov3.json"))
+    assert yj["fps"] == 8 and yj["total_frames"] == 9
+    got = {fr["frame"]: fr["detections"] for fr in yj["detections"]}
+    for fid in (0, 4, 8):
+        ref = OY.predict("n", 80, ysd, frames[fid], conf=0.5)
+        dets = got.get(fid, [])
+        assert abs(len(dets) - len(ref["src"])) <= max(2, len(ref["src"]) // 10), (fid, len(dets), len(ref["src"]))
+        if len(ref["src"]) and (len(ref["scores"]) < 2 or ref["scores"][0] - ref["scores"][1] > 1e-2):
+            assert dets[0]["class_id"] == int(ref["cls"][0])
+            assert np.allclose(dets[0]["bbox"], ref["boxes"][0], atol=3.0)
+            assert abs(dets[0]["confidence"] - float(ref["scores"][0])) < 2e-2
+    # SAM3: prompted with the service's own first detection; compare mask features with the oracle mask of the same prompt
+    assert [sg["frame"] for sg in sj["segmentations"]] == [0, 4, 8]
+    for sg in sj["segmentations"]:
+        fid = sg["frame"]
+        assert sg["mask_available"] == (fid in got)
+        if not sg["mask_available"]:
+            continue
+        box = np.array([got[fid][0]["bbox"]], np.float32)
+        with torch.no_grad():
+            fpn, _ = OH.encoder_forward(hcfg, hsd, torch.from_numpy(OP.sam_pixel_values(frames[fid], 1024))[None])
+            sp = OD.prompt_encode_box(msd, torch.from_numpy(OD.scale_box(box, (1080, 1920), (576, 1024))))
+            low, _ = OD.mask_decode(msd, fpn[2], sp)
+            mask = OD.postprocess(low, (576, 1024), (1080, 1920))[0].numpy()
+        ref = SP.extract_segmentation_features(mask)
+        f = sg["features"]
+        assert f["frame"] == fid and f["time"] == fid / 8
+        assert abs(f["mask_area"] - ref["mask_area"]) <= 0.002 * max(ref["mask_area"], 1) + 50
+        assert abs(f["centroid_x"] - ref["centroid_x"]) < 2 and abs(f["centroid_y"] - ref["centroid_y"]) < 2
+    # DINOv3: canonical frames = [first, middle, last] of the sampled frames (0, 8)
+    assert dj["embedding_dim"] == 256 and dj["num_embeddings"] == 2 and [c["frame"] for c in dj["canonical_frames"]] == [0, 8, 8]
+    for c in dj["canonical_frames"]:
+        with torch.no_grad():
+            ref = OV.embed(dcfg, dsd, torch.from_numpy(OP.dino_pixel_values(frames[c["frame"]]))[None])[0]
+        cos = torch.nn.functional.cosine_similarity(torch.tensor(c["embedding"], dtype=torch.float64), ref.double(), dim=0)
+        assert float(cos) > 1 - 1e-4

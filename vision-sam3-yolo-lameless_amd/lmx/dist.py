@@ -14,16 +14,12 @@ def shard_range(n_frames, rank, world):
 
 def gather_frame_records(rec):
     """rec: dict of per-frame tensors [n_local, ...] with identical n_local on every rank -> dict of [world*n_local, ...].
-    The big SAM image embedding stays local (it is an intermediate, not a per-clip output); boxes / scores / classes /
-    counts / DINO embeddings (and, later, bit-packed masks) are what the services persist."""
+    Boxes / scores / classes / counts, masks (+ their statistics) and DINO embeddings are what the services persist."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rec
     world = dist.get_world_size()
     out = {}
     for k, v in rec.items():
-        if k == "image_embedding":
-            out[k] = v
-            continue
         v = v.contiguous()
         g = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
         dist.all_gather_into_tensor(g, v)

@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from . import dino, sam, yolo
+from . import dino, sam, sam_decoder, yolo
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
 
@@ -22,15 +22,25 @@ class FusedExtractor:
                                       self.device)
         scfg = sam.hiera_b_plus()
         self.sam = sam.HieraEncoder(scfg, weights.synth_state_dict(sam.param_spec(scfg), weight_seeds[1]), self.device)
+        self.decoder = sam_decoder.MaskDecoder(sam_decoder.synthetic_state_dict(weight_seeds[1] + 100), self.device)
         dcfg = dino.dinov3_vitl16()
         self.dino = dino.DinoEmbedder(dcfg, weights.synth_state_dict(dino.param_spec(dcfg), weight_seeds[2]), self.device)
 
     def step(self, frames, conf=0.5, sam_chunk=16):
         """frames u8 [n,1080,1920,3] BGR on device -> dict of device tensors for every frame (dense schedule)."""
+        n, h, w, _ = frames.shape
         boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf)
         emb = self.dino.embed_frames(frames)
-        fpn2 = []
-        for i in range(0, frames.shape[0], sam_chunk):  # Hiera activations are ~100 MB/frame: bound the live set
-            out = self.sam.encode(frames[i:i + sam_chunk])
-            fpn2.append(out["fpn"][2])
-        return dict(boxes=boxes, scores=scores, cls=cls, counts=counts, embedding=emb, image_embedding=torch.cat(fpn2, 0))
+        rhw = sam.resize_longest_side(h, w, self.sam.cfg.image)
+        masks, stats, ious = [], [], []
+        for i in range(0, n, sam_chunk):  # Hiera activations are ~100 MB/frame: bound the live set
+            enc = self.sam.encode(frames[i:i + sam_chunk])
+            e2 = enc["fpn"][2]
+            # the service prompts SAM with the first (highest-confidence) detection of the frame (sam3 main.py:199-206);
+            # frames without a detection are decoded against an all-zero box and flagged by counts == 0
+            d = self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes[i:i + sam_chunk, 0, :], (h, w), rhw)
+            masks.append(d["mask"])
+            stats.append(d["stats"])
+            ious.append(d["iou"])
+        return dict(boxes=boxes, scores=scores, cls=cls, counts=counts, embedding=emb, mask=torch.cat(masks, 0),
+                    mask_stats=torch.cat(stats, 0), mask_iou=torch.cat(ious, 0))

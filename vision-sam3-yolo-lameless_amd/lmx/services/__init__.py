@@ -1,0 +1,8 @@
+"""Host-side mirror of the three hot-path services of the reference: same NATS subjects, same
+on-disk JSON schema (Appendix B), same sampling and quirks (Appendix C), with the third-party model call replaced by
+the liblmx path.  ``YOLOPipeline`` / ``SAM3Pipeline`` / ``DINOv3Pipeline`` keep the reference's class and method names
+(services/*/app/main.py); ``FusedFeatureService`` is the single-process, single-decode composition of the three."""
+from .dinov3_pipeline import DINOv3Pipeline  # noqa: F401
+from .fused import FusedFeatureService  # noqa: F401
+from .sam3_pipeline import SAM3Pipeline  # noqa: F401
+from .yolo_pipeline import YOLOPipeline  # noqa: F401

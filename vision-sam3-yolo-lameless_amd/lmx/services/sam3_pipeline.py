@@ -1,0 +1,147 @@
+"""SAM3Pipeline — mirror of services/sam3-pipeline/app/main.py: reads the YOLO result file (cache first), prompts with
+the FIRST detection of each sampled frame, writes `{id}_sam3.json` and publishes `pipeline.sam3` (Appendix B.2).
+`set_image` + `predict(box=...)` (main.py:80-88) are replaced by HieraEncoder.encode + MaskDecoder.predict; the 7 mask
+features come from lmx_h_mask_features on the host copy of the mask.  Without a segmenter the service falls back to the
+bbox rectangle exactly like the shipped reference (no checkpoint: main.py:68-69,94-100); a per-frame failure of the
+segmenter falls back the same way (main.py:90-92)."""
+import ctypes as C
+import json
+import traceback
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import runtime as R
+
+FEATURE_KEYS = ["mask_area", "area_ratio", "circularity", "aspect_ratio", "centroid_x", "centroid_y", "perimeter"]
+
+
+def extract_segmentation_features(mask):
+    """mask: bool/uint8 [h,w] on the HOST -> the 7-key dict of main.py:137-145."""
+    m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+    out = (C.c_double * 7)()
+    rc = _lib.load().lmx_h_mask_features(m.ctypes.data_as(C.c_void_p), m.shape[0], m.shape[1], C.cast(out, C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("lmx_h_mask_features failed")
+    return {k: float(v) for k, v in zip(FEATURE_KEYS, out)}
+
+
+def fallback_segmentation(shape_hw, bbox):
+    h, w = shape_hw
+    mask = np.zeros((h, w), dtype=np.uint8)
+    x1, y1, x2, y2 = [int(c) for c in bbox]
+    mask[y1:y2, x1:x2] = 255
+    return mask.astype(bool)
+
+
+class SAM3Pipeline:
+    def __init__(self, segmenter, bus, config=None, results_dir="/app/data/results/sam3", yolo_results_dir="/app/data/results/yolo",
+                 batch=16):
+        """segmenter: object with .device and .segment(frames_u8_device [n,h,w,3], boxes f32 device [n,4]) -> u8 masks
+        [n,h,w] on device, or None (rectangle fallback)."""
+        self.config = config or R.load_config()
+        self.nats_client = bus
+        self.sam_predictor = segmenter
+        self.results_dir = Path(results_dir)
+        self.results_dir.mkdir(parents=True, exist_ok=True)
+        self.yolo_results_dir = Path(yolo_results_dir)
+        self.yolo_results_cache = {}
+        self.batch = batch
+
+    async def get_yolo_results(self, video_id):
+        if video_id in self.yolo_results_cache:
+            return self.yolo_results_cache[video_id]
+        f = self.yolo_results_dir / f"{video_id}_yolo.json"
+        if f.exists():
+            with open(f) as fh:
+                res = json.load(fh)
+            self.yolo_results_cache[video_id] = res
+            return res
+        return {}
+
+    def _masks(self, clip, fids, boxes):
+        """-> list of host bool masks for the frames that have a box."""
+        h, w = clip.frames.shape[1:3]
+        if self.sam_predictor is None:
+            return [fallback_segmentation((h, w), b) for b in boxes]
+        out = []
+        dev = self.sam_predictor.device
+        for i in range(0, len(fids), self.batch):
+            ids, bx = fids[i:i + self.batch], boxes[i:i + self.batch]
+            try:
+                frames = torch.from_numpy(np.ascontiguousarray(clip.frames[ids])).to(dev)
+                m = self.sam_predictor.segment(frames, torch.tensor(bx, dtype=torch.float32, device=dev))
+                out += [a.astype(bool) for a in m.cpu().numpy()]
+            except Exception as e:  # noqa: BLE001
+                print(f"SAM3 segmentation error: {e}")
+                out += [fallback_segmentation((h, w), b) for b in bx]
+        return out
+
+    async def process_video(self, video_data):
+        video_id = video_data["video_id"]
+        processed_path = Path(video_data["processed_path"])
+        if not processed_path.exists():
+            print(f"Processed video not found: {processed_path}")
+            return
+        try:
+            yolo_results = await self.get_yolo_results(video_id)
+            clip = R.Clip.open(processed_path)
+            fps, total = clip.fps, clip.total_frames
+            ids = R.sampled(len(clip.frames), max(1, fps // 2))
+            by_frame = {}
+            if yolo_results and "detections" in yolo_results:
+                for det in yolo_results["detections"]:
+                    if det["frame"] not in by_frame and det["detections"]:
+                        by_frame[det["frame"]] = det["detections"][0]["bbox"]  # first = highest confidence (Appendix C-3)
+            with_box = [i for i in ids if by_frame.get(i)]
+            masks = dict(zip(with_box, self._masks(clip, with_box, [by_frame[i] for i in with_box])))
+            segmentations, frame_features = [], []
+            for i in ids:
+                t = i / fps if fps > 0 else 0
+                if i in masks:
+                    feats = extract_segmentation_features(masks[i])
+                    feats["frame"] = i
+                    feats["time"] = t
+                    frame_features.append(feats)
+                    segmentations.append({"frame": i, "time": t, "mask_available": True, "features": feats})
+                else:
+                    segmentations.append({"frame": i, "time": t, "mask_available": False})
+            avg = {}
+            if frame_features:
+                avg = {"avg_mask_area": float(np.mean([f["mask_area"] for f in frame_features])),
+                       "avg_area_ratio": float(np.mean([f["area_ratio"] for f in frame_features])),
+                       "avg_circularity": float(np.mean([f["circularity"] for f in frame_features])),
+                       "avg_aspect_ratio": float(np.mean([f["aspect_ratio"] for f in frame_features]))}
+            results = {"segmentations": segmentations, "aggregated_features": avg, "total_frames": total, "fps": fps,
+                       "frames_processed": len(segmentations)}
+            results_file = self.results_dir / f"{video_id}_sam3.json"
+            with open(results_file, "w") as f:
+                json.dump(results, f, indent=2)
+            await self.nats_client.publish(self.config["nats"]["subjects"]["pipeline_sam3"], {
+                "video_id": video_id, "pipeline": "sam3", "results_path": str(results_file), "features": avg,
+                "num_segmentations": len(segmentations)})
+        except Exception as e:  # noqa: BLE001
+            print(f"Error in SAM3 pipeline for {video_id}: {e}")
+            traceback.print_exc()
+
+    async def start(self):
+        await self.nats_client.connect()
+        await self.nats_client.subscribe(self.config["nats"]["subjects"]["video_preprocessed"], self.process_video)
+
+
+class HieraSegmenter:
+    """Adapter giving HieraEncoder + MaskDecoder the `segment(frames, boxes)` surface the service needs."""
+
+    def __init__(self, encoder, decoder):
+        self.encoder, self.decoder = encoder, decoder
+        self.device = encoder.device
+
+    def segment(self, frames, boxes):
+        from .. import sam
+
+        n, h, w, _ = frames.shape
+        enc = self.encoder.encode(frames)
+        e2 = enc["fpn"][2]
+        return self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes, (h, w), sam.resize_longest_side(h, w, self.encoder.cfg.image))["mask"]
