@@ -216,9 +216,10 @@ int lmx_k_prompt_box(const float* boxes, int64_t ldb, float* sparse, int n, doub
 int lmx_k_hyper_mask(const void* up, const float* hyper, float* logits, int n, int G, int C, lmx_stream_t stream);
 /* Sam.postprocess_masks + threshold + mask statistics: logits f32 [n][L][L] -> bilinear (align_corners=False) to
  * TxT, crop [:nh,:nw], bilinear to h x w, > 0  => mask u8 [n][h][w] (0/1);  stats int64 [n][8] =
- * (area, sum_x, sum_y, min_x, min_y, max_x, max_y, 0) over mask pixels (min/max = +-big when empty). */
+ * (area, sum_x, sum_y, min_x, min_y, max_x, max_y, 0) over mask pixels (min/max = +-big when empty).
+ * workspace: n*nh*nw floats (the cropped TxT intermediate, so each output pixel costs 4 taps instead of 16). */
 int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh, int nw, int h, int w, uint8_t* mask,
-                    int64_t* stats, lmx_stream_t stream);
+                    int64_t* stats, float* workspace, lmx_stream_t stream);
 
 /* ---- HOST function (mask pointer is HOST memory) ----------------------------------------------------------------------
  * extract_segmentation_features (sam3 main.py:102-145) on a 0/1 byte mask [h][w]: out[7] = mask_area, area_ratio,

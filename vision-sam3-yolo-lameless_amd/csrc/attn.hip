@@ -11,9 +11,15 @@
 //   O^T += V^T . P^T with a = V^T fragment, b = P^T fragment.  The MFMA k index is a free permutation as long as
 //         both operands agree, so k-slot (ks, g, j) is bound to key 32*ks + 16*(j>>2) + 4*g + (j&3): the P^T
 //         fragment is then exactly the lane's own S^T accumulators (no cross-lane movement, no LDS round trip;
-//         cdna guide §3 "An accumulator tile as the next MFMA's operand"), and V is written to LDS transposed in
-//         that slot order so its fragment is one ds_read_b128.
-// Both LDS images have 128-B rows with the 16-B chunk index XOR-swizzled by (row&7) (conflict-free b128 reads).
+//         cdna guide §3 "An accumulator tile as the next MFMA's operand").  V stays ROW-major in LDS (coalesced
+//         16-byte staging like K) and its fragment is two ds_read_b64_tr_b16 (hardware transpose, guide T10): the
+//         4 consecutive keys of each half-fragment are exactly one 4 x 16 transposed block.
+// Softmax is the VALU bottleneck at head dim 64 (16 MFMA cycles per score element-lane vs ~5 VALU + 1 exp), so:
+// scores stay raw and the scale is folded into one fma per element (exp2(s*c - m*c)); masking runs only on the last
+// tile; probabilities are packed with v_cvt_pk_f16_f32; the row sum is either free (head dim <= 56: V's unused
+// column 63 is set to 1, the PV MFMA accumulates the normaliser) or one v_dot2 per pair.
+// Both LDS images have 128-B rows with the 16-B chunk index XOR-swizzled by (row&7) (conflict-free reads), and are
+// double-buffered: one barrier per 64-key tile.
 #include "common.h"
 
 namespace {
@@ -45,10 +51,24 @@ __device__ __forceinline__ int64_t query_row(const Geo& g, int b, int t) {
   return ((int64_t)img * g.Gqh + y) * g.Gqw + x;
 }
 
-template <int QB>
-__global__ __launch_bounds__(256) void attn_kernel(const lmx_attn_desc p, const Geo geo, const int nQT) {
-  __shared__ __attribute__((aligned(16))) half_t Ks[64 * 64];
-  __shared__ __attribute__((aligned(16))) half_t Vt[64 * 64];
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4_t* lds_f16x4_ptr;
+
+// ds_read_b64_tr_b16: per 16-lane group, a 4(rows) x 16(cols) block of halfs is delivered column-major (lane i gets
+// column i of the 4 rows).  Needs EXEC all ones and 8-byte aligned addresses (cdna guide §5.5 T10).
+__device__ __forceinline__ half4_t lds_tr_read(const half_t* p) {
+  const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_ptr)(p));
+  half4_t h;
+  __builtin_memcpy(&h, &v, 8);
+  return h;
+}
+
+// QB: 16-query blocks per wave.  ONES: head dim <= 56, so V's (zero) column 63 is set to 1 and the PV MFMA itself
+// accumulates the softmax normaliser in O[:,63] — no row-sum instructions at all.
+template <int QB, bool ONES>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, const Geo geo, const int nQT) {
+  __shared__ __attribute__((aligned(16))) half_t Ks[2][64 * 64];
+  __shared__ __attribute__((aligned(16))) half_t Vs[2][64 * 64];  // row-major [key][d], same swizzle as K
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -79,9 +99,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const lmx_attn_desc p, const 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int d = ks * 32 + fg * 8;
-      qf[qb][ks] = (qrow[qb] >= 0 && d < hd)
-                       ? *reinterpret_cast<const half8_t*>(Q + qrow[qb] * p.ldq + (int64_t)h * hd + d)
-                       : zero8;
+      const bool ok = qrow[qb] >= 0 && d < hd;
+      const half8_t qv = *reinterpret_cast<const half8_t*>(Q + (ok ? qrow[qb] * p.ldq + (int64_t)h * hd + d : 0));
+      qf[qb][ks] = ok ? qv : zero8;
     }
   }
 
@@ -95,56 +115,73 @@ __global__ __launch_bounds__(256) void attn_kernel(const lmx_attn_desc p, const 
     for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- staging assignment: chunk c of key kk = (tid>>3) + 32*i
+  // ---- staging assignment: chunk sc of key kk = sk + 32*i
   const int sc = tid & 7;
   const int sk = tid >> 3;
   half8_t kst[2], vst[2];
+  // per-thread base pointers: everything that does not depend on the key index is hoisted out of the tile loop
+  const int64_t hoff0 = (int64_t)h * hd + sc * 8;
+  const half_t* Kb = K + hoff0 + (geo.mode == 0 ? (int64_t)b * p.Tk * p.ldk : 0);
+  const half_t* Vb = V + hoff0 + (geo.mode == 0 ? (int64_t)b * p.Tk * p.ldv : 0);
+  const bool d_ok = sc * 8 < hd;
   auto load_tile = [&](int t0) {
+    if (geo.mode == 0) {  // flat geometry (wave-uniform branch): row = b*Tk + t, no padding keys
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int t = t0 + sk + 32 * i;
+        const bool in = d_ok && t < p.Tk;
+        const int tt = in ? t : 0;
+        const half8_t kv = *reinterpret_cast<const half8_t*>(Kb + (int64_t)tt * p.ldk);
+        const half8_t vv = *reinterpret_cast<const half8_t*>(Vb + (int64_t)tt * p.ldv);
+        kst[i] = in ? kv : zero8;
+        vst[i] = in ? vv : zero8;
+        if (ONES && sc == 7 && t < p.Tk) vst[i][7] = (half_t)1.0f;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int t = t0 + sk + 32 * i;
       const int d = sc * 8;
-      kst[i] = zero8;
-      vst[i] = zero8;
-      if (t < p.Tk && d < hd) {
-        const int64_t row = key_row(geo, b, t);
-        if (row >= 0) {
-          kst[i] = *reinterpret_cast<const half8_t*>(K + row * p.ldk + (int64_t)h * hd + d);
-          vst[i] = *reinterpret_cast<const half8_t*>(V + row * p.ldv + (int64_t)h * hd + d);
-        } else {
-          if (padk) kst[i] = *reinterpret_cast<const half8_t*>(padk + (int64_t)h * hd + d);
-          if (padv) vst[i] = *reinterpret_cast<const half8_t*>(padv + (int64_t)h * hd + d);
-        }
-      }
+      // branch-free: every lane always loads 16 bytes from SOME valid address and the result is selected afterwards.
+      // (Loads under divergent `if`s made hipcc wait for each one in turn: ~4 exposed HBM/L2 latencies per tile.)
+      const bool in = (t < p.Tk) && (d < hd);
+      const int64_t row = key_row(geo, b, in ? t : 0);
+      const bool pad = row < 0;
+      const int64_t hoff = (int64_t)h * hd + d;
+      const half_t* kp = pad ? (padk ? padk + hoff : K) : K + (in ? row * p.ldk + hoff : 0);
+      const half_t* vp = pad ? (padv ? padv + hoff : V) : V + (in ? row * p.ldv + hoff : 0);
+      const half8_t kv = *reinterpret_cast<const half8_t*>(kp);
+      const half8_t vv = *reinterpret_cast<const half8_t*>(vp);
+      kst[i] = (in && (!pad || padk)) ? kv : zero8;
+      vst[i] = (in && (!pad || padv)) ? vv : zero8;
+      if (ONES && sc == 7 && t < p.Tk) vst[i][7] = (half_t)1.0f;  // column 63 of every real key: PV sums the probabilities
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int kk = sk + 32 * i;
-      *reinterpret_cast<half8_t*>(Ks + kk * 64 + ((sc ^ (kk & 7)) << 3)) = kst[i];
-      // V^T in k-slot order: key kk -> slot = 32*ks + 8*g + 4*jhi + jlo
-      const int ks = kk >> 5, rem = kk & 31, jhi = rem >> 4, g = (rem & 15) >> 2, jlo = rem & 3;
-      const int chunk = ks * 4 + g, within = jhi * 4 + jlo;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int d = sc * 8 + e;
-        Vt[d * 64 + ((chunk ^ (d & 7)) << 3) + within] = vst[i][e];
-      }
+      const int off = kk * 64 + ((sc ^ (kk & 7)) << 3);
+      *reinterpret_cast<half8_t*>(&Ks[buf][off]) = kst[i];
+      *reinterpret_cast<half8_t*>(&Vs[buf][off]) = vst[i];
     }
   };
 
-  const float sl2 = p.scale * 1.44269504088896340736f;  // scores are kept in log2 units
+  const float sl2 = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*sl2)
   const int ntile = (p.Tk + 63) / 64;
+  // transposed-read addressing of the V fragment: lane (q4 = (lane&15)>>2, p4 = lane&3) of a 16-lane group points at
+  // row key0+q4, columns 16*db + 4*p4 .. +3
+  const int q4 = fr >> 2, p4 = fr & 3;
   load_tile(0);
+  store_tile(0);
+  __syncthreads();
   for (int it = 0; it < ntile; ++it) {
     const int t0 = it * 64;
-    __syncthreads();  // previous tile's readers are done
-    store_tile();
-    __syncthreads();
+    const int buf = it & 1;
     if (it + 1 < ntile) load_tile(t0 + 64);
 
-    // ---- S^T = K . Q^T
+    // ---- S^T = K . Q^T  (raw, unscaled)
     f32x4 sacc[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
@@ -155,68 +192,84 @@ __global__ __launch_bounds__(256) void attn_kernel(const lmx_attn_desc p, const 
       const int coff = (((ks << 2) + fg) ^ (fr & 7)) << 3;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kb * 16 + fr) * 64 + coff);
+        const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[buf][(kb * 16 + fr) * 64 + coff]);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
           sacc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qb][ks], sacc[qb][kb], 0, 0, 0);
       }
     }
 
-    // ---- online softmax (per query = per lane column), P^T fragments straight from the accumulators
+    // ---- online softmax (per query = per lane column); P^T fragments come straight from the accumulators
+    const bool partial = t0 + 64 > p.Tk;  // only the last tile can hold keys >= Tk
     half8_t pf[QB][2];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      float mx = -INFINITY;
+      if (partial) {
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = t0 + kb * 16 + fg * 4 + r;
-          float s = sacc[qb][kb][r] * sl2;
-          s = key < p.Tk ? s : -INFINITY;
-          sacc[qb][kb][r] = s;
-          mx = fmaxf(mx, s);
-        }
+          for (int r = 0; r < 4; ++r)
+            if (t0 + kb * 16 + fg * 4 + r >= p.Tk) sacc[qb][kb][r] = -INFINITY;
+      }
+      float mx = fmaxf(fmaxf(sacc[qb][0][0], sacc[qb][0][1]), fmaxf(sacc[qb][0][2], sacc[qb][0][3]));
+#pragma unroll
+      for (int kb = 1; kb < 4; ++kb)
+        mx = fmaxf(mx, fmaxf(fmaxf(sacc[qb][kb][0], sacc[qb][kb][1]), fmaxf(sacc[qb][kb][2], sacc[qb][kb][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[qb], mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * sl2);
       m_run[qb] = m_new;
+      const float mb = m_new * sl2;
       float rs = 0.f;
+      const half2_t ones2 = {(half_t)1.0f, (half_t)1.0f};
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(sacc[qb][kb][r] - m_new);
-          const half_t eh = (half_t)e;
-          rs += (float)eh;  // the normaliser sums exactly what the PV MFMA sees
-          pf[qb][kb >> 1][(kb & 1) * 4 + r] = eh;
+        for (int r = 0; r < 4; r += 2) {
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r], sl2, -mb));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r + 1], sl2, -mb));
+          const half2_t e = {(half_t)e0, (half_t)e1};
+          if (!ONES) rs = __builtin_amdgcn_fdot2(e, ones2, rs, false);  // sums exactly what the PV MFMA sees
+          pf[qb][kb >> 1][(kb & 1) * 4 + r] = e[0];
+          pf[qb][kb >> 1][(kb & 1) * 4 + r + 1] = e[1];
         }
-      l_run[qb] = l_run[qb] * alpha + rs;
+      if (!ONES) l_run[qb] = l_run[qb] * alpha + rs;
 #pragma unroll
       for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
     }
 
-    // ---- O^T += V^T . P^T
+    // ---- O^T += V^T . P^T   (V^T fragments by hardware-transposed LDS reads of the row-major V tile)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        const int d = db * 16 + fr;
-        const half8_t vf = *reinterpret_cast<const half8_t*>(Vt + d * 64 + ((((ks << 2) + fg) ^ (d & 7)) << 3));
+        const int chunk = db * 2 + (p4 >> 1);
+        const int r0 = ks * 32 + fg * 4 + q4, r1 = r0 + 16;
+        const half4_t lo = lds_tr_read(&Vs[buf][r0 * 64 + ((chunk ^ (r0 & 7)) << 3) + (p4 & 1) * 4]);
+        const half4_t hi = lds_tr_read(&Vs[buf][r1 * 64 + ((chunk ^ (r1 & 7)) << 3) + (p4 & 1) * 4]);
+        const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
           oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][ks], oacc[qb][db], 0, 0, 0);
       }
     }
+
+    if (it + 1 < ntile) store_tile(buf ^ 1);
+    __syncthreads();
   }
 
   // ---- epilogue: lane owns O[q = fr][d = 16*db + 4*fg + r]
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    float l = l_run[qb];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if (ONES) {
+      l = __shfl(oacc[qb][3][3], 48 + fr, 64);  // O[q][63] lives in lane group 3, register 3 of the last d-block
+    } else {
+      l = l_run[qb];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.0f / l;
     if (qrow[qb] < 0) continue;
 #pragma unroll
@@ -273,9 +326,14 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   const int nQT = (d.Tq + qtile - 1) / qtile;
   const int64_t nblk = (int64_t)d.B * d.H * nQT;
   LMX_REQUIRE(nblk < (1ll << 31), "lmx_k_attention: grid too large");
-  if (big)
-    hipLaunchKernelGGL((attn_kernel<2>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  const bool ones = d.hd <= 56;
+  if (big && ones)
+    hipLaunchKernelGGL((attn_kernel<2, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  else if (big)
+    hipLaunchKernelGGL((attn_kernel<2, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  else if (ones)
+    hipLaunchKernelGGL((attn_kernel<1, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else
-    hipLaunchKernelGGL((attn_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    hipLaunchKernelGGL((attn_kernel<1, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   return lmx_launch_check("attn_kernel");
 }

@@ -179,37 +179,84 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
     }
   }
 
-  // epilogue: lane owns row m (lane&15), 4 consecutive channels n (lane>>4)*4 per fragment
+  // ---- epilogue through LDS.  In the accumulator a lane owns 4 channels of 16 different rows, so direct stores are
+  // 8-byte pieces at a row stride (16 store instructions per wave, 32-byte segments).  Each wave instead transposes its
+  // 64 x 64 tile through its own slice of the (now idle) staging LDS and writes whole 128-/256-byte row segments with
+  // 16-byte lane stores; the residual is read in the same coalesced shape.  bias / activation / LayerScale are applied
+  // in registers on the way in.
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the last k-tile
   const int act = p.act;
+  char* my = smem + wave * 4608;  // 32 rows x 144 B (f16) or 16 rows x 272 B (f32) per pass
+  f32x4 bia[4], scl[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + frow;
-    if (m >= p.M) continue;
-    const int mr = p.res_rows > 0 ? m % p.res_rows : m;
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + fq * 4;
+    bia[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    scl[j] = (p.scale && n < p.N) ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+  }
+  if (OUT_DT == LMX_F16) {
+    half_t* t16 = reinterpret_cast<half_t*>(my);
+    constexpr int RS = 72;  // halfs per LDS row: 64 + 8 (16-byte pad keeps ds_read_b128 aligned and spreads banks)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fq * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-      if (act != LMX_ACT_NONE) {
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
-      }
-      if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + n);
-      if (OUT_DT == LMX_F32) {
-        if (p.res) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)mr * p.ldr + n);
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = v;
-      } else {
-        if (p.res) {
-          const half4_t rr = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.res) + (int64_t)mr * p.ldr + n);
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v = acc[pass * 2 + ii][j] + bia[j];
+          if (act != LMX_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
+          }
+          v *= scl[j];
+          const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<half4_t*>(t16 + (ii * 16 + frow) * RS + j * 16 + fq * 4) = o;
         }
-        half4_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-        *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+        half8_t o = *reinterpret_cast<const half8_t*>(t16 + row * RS + c8 * 8);
+        const int m = m0 + wm * 64 + pass * 32 + row;
+        const int n = n0 + wn * 64 + c8 * 8;
+        if (m < p.M && n < p.N) {
+          if (p.res) {
+            const int mr = p.res_rows > 0 ? m % p.res_rows : m;
+            const half8_t rr = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.res) + (int64_t)mr * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
+          }
+          *reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
+        }
+      }
+    }
+  } else {
+    float* t32 = reinterpret_cast<float*>(my);
+    constexpr int RS = 68;  // floats per LDS row: 64 + 4
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = acc[pass][j] + bia[j];
+        if (act != LMX_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
+        }
+        v *= scl[j];
+        *reinterpret_cast<f32x4*>(t32 + frow * RS + j * 16 + fq * 4) = v;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 4 + (lane >> 4), c16 = lane & 15;
+        f32x4 o = *reinterpret_cast<const f32x4*>(t32 + row * RS + c16 * 4);
+        const int m = m0 + wm * 64 + pass * 16 + row;
+        const int n = n0 + wn * 64 + c16 * 4;
+        if (m < p.M && n < p.N) {
+          if (p.res) {
+            const int mr = p.res_rows > 0 ? m % p.res_rows : m;
+            o += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)mr * p.ldr + n);
+          }
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
+        }
       }
     }
   }

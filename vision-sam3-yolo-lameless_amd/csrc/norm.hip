@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const void* __res
   }
 }
 
-template <int IN_DT, int OUT_DT>
+template <int IN_DT, int OUT_DT, int ITERS>  // ITERS float4 per lane: D <= 256*ITERS (fewer registers -> more rows in flight)
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ xv, int64_t ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ yv,
@@ -60,10 +60,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  f32x4 v[16];
+  f32x4 v[ITERS];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < ITERS; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < D) {
       if (IN_DT == LMX_F32) {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < ITERS; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < D) {
       const f32x4 dlt = v[i] - mean;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < ITERS; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < D) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -220,16 +220,29 @@ extern "C" int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const f
     return lmx_launch_check("layernorm_narrow_kernel");
   }
   dim3 grid((rows + 3) / 4), block(256);
+#define LMX_LN(IN, OUT, IT) \
+  hipLaunchKernelGGL((layernorm_kernel<IN, OUT, IT>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act)
+#define LMX_LN_IT(IN, OUT)        \
+  do {                            \
+    if (D <= 512)                 \
+      LMX_LN(IN, OUT, 2);         \
+    else if (D <= 1024)           \
+      LMX_LN(IN, OUT, 4);         \
+    else                          \
+      LMX_LN(IN, OUT, 16);        \
+  } while (0)
   if (in_dtype == LMX_F32 && out_dtype == LMX_F16)
-    hipLaunchKernelGGL((layernorm_kernel<LMX_F32, LMX_F16>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+    LMX_LN_IT(LMX_F32, LMX_F16);
   else if (in_dtype == LMX_F32 && out_dtype == LMX_F32)
-    hipLaunchKernelGGL((layernorm_kernel<LMX_F32, LMX_F32>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+    LMX_LN_IT(LMX_F32, LMX_F32);
   else if (in_dtype == LMX_F16 && out_dtype == LMX_F16)
-    hipLaunchKernelGGL((layernorm_kernel<LMX_F16, LMX_F16>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+    LMX_LN_IT(LMX_F16, LMX_F16);
   else if (in_dtype == LMX_F16 && out_dtype == LMX_F32)
-    hipLaunchKernelGGL((layernorm_kernel<LMX_F16, LMX_F32>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act);
+    LMX_LN_IT(LMX_F16, LMX_F32);
   else
     LMX_REQUIRE(false, "lmx_k_layernorm: bad dtypes %d -> %d", in_dtype, out_dtype);
+#undef LMX_LN_IT
+#undef LMX_LN
   return lmx_launch_check("layernorm_kernel");
 }
 

@@ -157,12 +157,26 @@ __device__ __forceinline__ float sample_mid(const float* __restrict__ lg, int L,
   return (1.f - ly) * t0 + ly * t1;
 }
 
-__global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict__ logits, int n, int L, int T, int nh, int nw,
-                                                        int h, int w, uint8_t* __restrict__ mask,
-                                                        unsigned long long* __restrict__ stats) {
+// pass 1: the T x T bilinear upsample of the L x L logits, only the [nh][nw] crop that pass 2 reads
+__global__ __launch_bounds__(256) void mask_mid_kernel(const float* __restrict__ logits, float* __restrict__ mid, int n, int L,
+                                                       int T, int nh, int nw) {
+  const float sLT = (float)L / (float)T;
+  const int64_t total = (int64_t)n * nh * nw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int X = (int)(i % nw);
+    const int64_t r = i / nw;
+    const int Y = (int)(r % nh);
+    const int b = (int)(r / nh);
+    mid[i] = sample_mid(logits + (int64_t)b * L * L, L, T, sLT, Y, X);
+  }
+}
+
+// pass 2: bilinear [nh][nw] -> [h][w], > 0, statistics
+__global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict__ mid, int n, int nh, int nw, int h, int w,
+                                                        uint8_t* __restrict__ mask, unsigned long long* __restrict__ stats) {
   const int b = blockIdx.y;
-  const float* lg = logits + (int64_t)b * L * L;
-  const float sLT = (float)L / (float)T, sy = (float)nh / (float)h, sx = (float)nw / (float)w;
+  const float* md = mid + (int64_t)b * nh * nw;
+  const float sy = (float)nh / (float)h, sx = (float)nw / (float)w;
   unsigned long long area = 0, sumx = 0, sumy = 0;
   int minx = 0x7fffffff, miny = 0x7fffffff, maxx = -1, maxy = -1;
   const int64_t total = (int64_t)h * w;
@@ -172,9 +186,8 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
     float ly, lx;
     bil_idx(sy, y, nh, Y0, Y1, ly);
     bil_idx(sx, x, nw, X0, X1, lx);
-    const float v00 = sample_mid(lg, L, T, sLT, Y0, X0), v01 = sample_mid(lg, L, T, sLT, Y0, X1);
-    const float v10 = sample_mid(lg, L, T, sLT, Y1, X0), v11 = sample_mid(lg, L, T, sLT, Y1, X1);
-    const float t0 = (1.f - lx) * v00 + lx * v01, t1 = (1.f - lx) * v10 + lx * v11;
+    const float t0 = (1.f - lx) * md[Y0 * nw + X0] + lx * md[Y0 * nw + X1];
+    const float t1 = (1.f - lx) * md[Y1 * nw + X0] + lx * md[Y1 * nw + X1];
     const float v = (1.f - ly) * t0 + ly * t1;
     const bool on = v > 0.0f;
     mask[(int64_t)b * total + i] = on ? 1 : 0;
@@ -319,14 +332,15 @@ extern "C" int lmx_k_hyper_mask(const void* up, const float* hyper, float* logit
 }
 
 extern "C" int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh, int nw, int h, int w, uint8_t* mask, int64_t* stats,
-                               lmx_stream_t stream) {
-  LMX_REQUIRE(logits && mask && stats, "lmx_k_mask_post: null pointer");
+                               float* workspace, lmx_stream_t stream) {
+  LMX_REQUIRE(logits && mask && stats && workspace, "lmx_k_mask_post: null pointer");
   LMX_REQUIRE(n > 0 && L > 0 && T >= L && nh > 0 && nw > 0 && nh <= T && nw <= T && h > 0 && w > 0, "lmx_k_mask_post: geometry");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, st, reinterpret_cast<long long*>(stats), n);
   int gx = (int)(((int64_t)h * w + 255) / 256);
   if (gx > 1024) gx = 1024;
-  hipLaunchKernelGGL(mask_post_kernel, dim3(gx, n), dim3(256), 0, st, logits, n, L, T, nh, nw, h, w, mask,
+  hipLaunchKernelGGL(mask_mid_kernel, dim3(grid_for((int64_t)n * nh * nw)), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw);
+  hipLaunchKernelGGL(mask_post_kernel, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask,
                      reinterpret_cast<unsigned long long*>(stats));
   return lmx_launch_check("mask_post_kernel");
 }

@@ -66,7 +66,7 @@ SIGNATURES = {
     "lmx_h_mask_features": (_I, [_VP, _I, _I, _VP]),
     "lmx_k_prompt_box": (_I, [_VP, _I64, _VP, _I, _D, _D, _F, _VP, _VP, _I, _VP]),
     "lmx_k_hyper_mask": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
-    "lmx_k_mask_post": (_I, [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "lmx_k_mask_post": (_I, [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
 }
 
 _lib = None

@@ -387,7 +387,9 @@ def mask_post(logits, T, nh, nw, h, w):
     n, L, _ = logits.shape
     mask = torch.empty((n, h, w), dtype=torch.uint8, device=logits.device)
     stats = torch.empty((n, 8), dtype=torch.int64, device=logits.device)
-    check(_lib.load().lmx_k_mask_post(_ptr(logits), n, L, T, nh, nw, h, w, _ptr(mask), _ptr(stats), _stream()), "lmx_k_mask_post")
+    ws = torch.empty((n, nh, nw), dtype=torch.float32, device=logits.device)
+    check(_lib.load().lmx_k_mask_post(_ptr(logits), n, L, T, nh, nw, h, w, _ptr(mask), _ptr(stats), _ptr(ws), _stream()),
+          "lmx_k_mask_post")
     return mask, stats
 
 
