@@ -102,6 +102,30 @@ def test_conv_channel_slices_and_residual(cuda):
     _close(got1, ref1, 5e-3, 5e-3, "conv1x1")
 
 
+def test_conv_lds_dma_path_slices_residual_stride2(cuda):
+    """Shapes that take the 256x128 LDS-DMA kernel (M >= 512, Cout >= 96, Cin % 32 == 0): slice in/out, shortcut, stride 2,
+    a tile spanning two images, M not a multiple of the tile."""
+    from lmx import kernels as Kk
+
+    n, H, W, C = 3, 24, 20, 128
+    buf = _rand((n, H, W, 3 * C), 17).half()
+    w = _rand((C, C, 3, 3), 18, (9 * C) ** -0.5).half()
+    b = _rand((C,), 19, 0.1)
+    xin = buf[..., C:2 * C]
+    ref = buf.clone().float()
+    y = F.silu(F.conv2d(xin.float().permute(0, 3, 1, 2), w.float(), b, padding=1)).permute(0, 2, 3, 1)
+    ref[..., 2 * C:] = y + xin.float()
+    d = buf.to(cuda)
+    wp = w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous().to(cuda)
+    Kk.conv3x3(d[..., C:2 * C], wp, bias=b.to(cuda), res=d[..., C:2 * C], out=d[..., 2 * C:])
+    _close(d, ref, 4e-3, 3e-3, "lds-dma conv slice/residual")
+    x2 = _rand((2, 47, 33, 64), 20).half()
+    w2 = _rand((96, 64, 3, 3), 21, (9 * 64) ** -0.5).half()
+    ref2 = F.silu(F.conv2d(x2.float().permute(0, 3, 1, 2), w2.float(), None, stride=2, padding=1)).permute(0, 2, 3, 1)
+    got2 = Kk.conv3x3(x2.to(cuda), w2.permute(0, 2, 3, 1).reshape(96, 576).contiguous().to(cuda), act=Kk.ACT_SILU, stride=2)
+    _close(got2, ref2, 4e-3, 3e-3, "lds-dma conv stride 2")
+
+
 # ------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("rows,D", [(5, 112), (201, 1024), (64, 1280), (3, 4096)])
 def test_layernorm(cuda, rows, D):

@@ -21,6 +21,7 @@
 // Both LDS images have 128-B rows with the 16-B chunk index XOR-swizzled by (row&7) (conflict-free reads), and are
 // double-buffered: one barrier per 64-key tile.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -176,7 +177,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
   load_tile(0);
   store_tile(0);
   __syncthreads();
-  for (int it = 0; it < ntile; ++it) {
+  // The body is instantiated twice: full tiles carry NO masking code at all (hipcc otherwise if-converts the
+  // wave-uniform `partial` test into a compare+select per score element: ~60 VALU per tile), the last tile masks.
+  auto tile_body = [&](const int it, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const int t0 = it * 64;
     const int buf = it & 1;
     if (it + 1 < ntile) load_tile(t0 + 64);
@@ -200,11 +204,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
     }
 
     // ---- online softmax (per query = per lane column); P^T fragments come straight from the accumulators
-    const bool partial = t0 + 64 > p.Tk;  // only the last tile can hold keys >= Tk
     half8_t pf[QB][2];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      if (partial) {
+      if (MASK) {  // only the last tile can hold keys >= Tk
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -257,7 +260,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
 
     if (it + 1 < ntile) store_tile(buf ^ 1);
     __syncthreads();
-  }
+  };
+  for (int it = 0; it + 1 < ntile; ++it) tile_body(it, std::false_type{});
+  if (p.Tk & 63)
+    tile_body(ntile - 1, std::true_type{});
+  else
+    tile_body(ntile - 1, std::false_type{});
 
   // ---- epilogue: lane owns O[q = fr][d = 16*db + 4*fg + r]
 #pragma unroll
@@ -321,6 +329,7 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
     LMX_REQUIRE(d.mode == 0, "lmx_k_attention: bad mode %d", d.mode);
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
   const bool big = d.Tq > 64;
   const int qtile = big ? 128 : 64;
   const int nQT = (d.Tq + qtile - 1) / qtile;

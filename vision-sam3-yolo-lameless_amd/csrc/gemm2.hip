@@ -68,7 +68,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // BM x 128 x BK tile, NSTAGE-slot LDS ring, (BM/64) x 2 waves of 64 x 64 outputs.
-template <int OUT_DT, int BM, int BK, int NSTAGE, int MINW>
+// AMODE 1: A is generated from an NHWC image batch (3x3, pad 1, stride 1|2; gemm.hip's a_mode 1) — requires Cin % BK == 0
+// so that a k-tile lies inside one filter tap: the tap (ky,kx) is then wave-uniform per k-tile and a lane only adds a
+// constant to its pixel offset; out-of-image taps take the out-of-range offset and the descriptor returns zeros.
+template <int OUT_DT, int BM, int BK, int NSTAGE, int AMODE>
 __global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
   constexpr int NWAVE = BM / 32;
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
@@ -91,9 +94,13 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
   const int m0 = mt * BM, n0 = nt * BN;
 
   // buffer descriptors over this block's row panels: the hardware range check returns 0 beyond the last valid byte
-  const char* Ab = reinterpret_cast<const char*>(p.A) + (int64_t)m0 * p.lda * 2;
+  const int hw_out = (AMODE == 1) ? p.Ho * p.Wo : 1;
+  const int img0 = (AMODE == 1) ? m0 / hw_out : 0;  // first image touched by this tile
+  const char* Ab = reinterpret_cast<const char*>(p.A) +
+                   ((AMODE == 1) ? (int64_t)img0 * p.H * p.W_ * p.lda * 2 : (int64_t)m0 * p.lda * 2);
   const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.K * 2;
-  int64_t a_bytes = ((int64_t)(p.M - m0 - 1) * p.lda + p.K) * 2;
+  int64_t a_bytes = (AMODE == 1) ? ((int64_t)(p.M / hw_out - img0) * p.H * p.W_ - 1) * p.lda * 2 + (int64_t)p.Cin * 2
+                                 : ((int64_t)(p.M - m0 - 1) * p.lda + p.K) * 2;
   int64_t w_bytes = (int64_t)(p.N - n0) * p.K * 2;
   if (a_bytes > 0x7FFFFFF0ll) a_bytes = 0x7FFFFFF0ll;
   if (w_bytes > 0x7FFFFFF0ll) w_bytes = 0x7FFFFFF0ll;
@@ -107,9 +114,23 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
   const int lsw = (BK == 64) ? (lrow & 7) : ((-(lrow >> 2)) & 3);
   const int lchunk = (lane % CHUNKS) ^ lsw;
   unsigned a_off[A_INSTR], w_off[W_INSTR];
+  int a_yx[A_INSTR];  // AMODE 1: (iy0 << 16) | (ix0 & 0xffff) of the row's top-left tap, -1 for rows >= M
 #pragma unroll
-  for (int j = 0; j < A_INSTR; ++j)
-    a_off[j] = (unsigned)(((wave * A_INSTR + j) * ROWS_PER_INSTR + lrow) * (int)p.lda * 2 + lchunk * 16);
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int row = (wave * A_INSTR + j) * ROWS_PER_INSTR + lrow;
+    if (AMODE == 0) {
+      a_off[j] = (unsigned)(row * (int)p.lda * 2 + lchunk * 16);
+      a_yx[j] = 0;
+    } else {
+      const int m = m0 + row;
+      const int img = m / hw_out, rem = m - img * hw_out;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.conv_stride - 1, ix0 = ox * p.conv_stride - 1;
+      // offset of the (possibly out-of-image) top-left tap relative to image img0; valid taps always land >= 0
+      a_off[j] = (unsigned)((((img - img0) * p.H + iy0) * p.W_ + ix0) * (int)p.lda * 2 + lchunk * 16);
+      a_yx[j] = (m < p.M) ? ((iy0 << 16) | (ix0 & 0xffff)) : 0x80008000;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < W_INSTR; ++j)
     w_off[j] = (unsigned)(((wave * W_INSTR + j) * ROWS_PER_INSTR + lrow) * p.K * 2 + lchunk * 16);
@@ -121,10 +142,24 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
     char* st = smem + slot * STAGE_BYTES;
     const bool kill = (kt == nk - 1) && k_tail_lane;
     const int soff = kt * (BK * 2);
+    if (AMODE == 0) {
 #pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-      char* dst = st + (wave * A_INSTR + j) * 1024;
-      lds_dma16(a_rs, dst, kill ? OOB : a_off[j], soff);
+      for (int j = 0; j < A_INSTR; ++j) {
+        char* dst = st + (wave * A_INSTR + j) * 1024;
+        lds_dma16(a_rs, dst, kill ? OOB : a_off[j], soff);
+      }
+    } else {
+      const int k0 = kt * BK;          // wave-uniform: the whole k-tile sits in one filter tap
+      const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int tap_off = ((ky * p.W_ + kx) * (int)p.lda + ci0) * 2;
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) {
+        char* dst = st + (wave * A_INSTR + j) * 1024;
+        const int iy = (a_yx[j] >> 16) + ky, ix = (int)(short)(a_yx[j] & 0xffff) + kx;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W_;
+        lds_dma16(a_rs, dst, ok ? a_off[j] + (unsigned)tap_off : OOB, 0);
+      }
     }
 #pragma unroll
     for (int j = 0; j < W_INSTR; ++j) {
@@ -262,22 +297,22 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
   }
 }
 
-template <int BM, int BK, int NSTAGE, int MINW>
+template <int BM, int BK, int NSTAGE, int AMODE>
 int launch2(const lmx_gemm_desc& d, hipStream_t st) {
   const int MT = (d.M + BM - 1) / BM, NT = (d.N + BN - 1) / BN;
   const size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F16, BM, BK, NSTAGE, MINW>),
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F16, BM, BK, NSTAGE, AMODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F32, BM, BK, NSTAGE, MINW>),
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F32, BM, BK, NSTAGE, AMODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
   if (d.out_dtype == LMX_F16)
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BK, NSTAGE, MINW>), dim3(MT * NT), dim3(BM * 2), smem, st, d);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BK, NSTAGE, AMODE>), dim3(MT * NT), dim3(BM * 2), smem, st, d);
   else
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BK, NSTAGE, MINW>), dim3(MT * NT), dim3(BM * 2), smem, st, d);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BK, NSTAGE, AMODE>), dim3(MT * NT), dim3(BM * 2), smem, st, d);
   return lmx_launch_check("gemm2_kernel");
 }
 
@@ -293,14 +328,15 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     const char* e = getenv("LMX_GEMM2_VARIANT");
     variant = e ? e[0] : 0;
   }
+  if (d.a_mode == 1) return launch2<256, 32, 3, 1>(d, st);  // 3x3 convolution, Cin % 32 == 0 (checked by the caller)
   switch (variant) {
-    case 'A': return launch2<256, 64, 3, 2>(d, st);
-    case 'B': return launch2<128, 64, 2, 2>(d, st);
-    case 'C': return launch2<256, 32, 3, 4>(d, st);
-    case 'D': return launch2<256, 32, 2, 4>(d, st);
+    case 'A': return launch2<256, 64, 3, 0>(d, st);
+    case 'B': return launch2<128, 64, 2, 0>(d, st);
+    case 'C': return launch2<256, 32, 3, 0>(d, st);
+    case 'D': return launch2<256, 32, 2, 0>(d, st);
     default:
       // measured on the model shapes (profiles/r01_gemm_variants.txt): with K <= ~2k the per-tile prologue/epilogue
       // dominates and two co-resident blocks (C) hide it; long-K problems prefer the deeper 64-wide ring (A)
-      return d.K >= 3072 ? launch2<256, 64, 3, 2>(d, st) : launch2<256, 32, 3, 4>(d, st);
+      return d.K >= 3072 ? launch2<256, 64, 3, 0>(d, st) : launch2<256, 32, 3, 0>(d, st);
   }
 }
