@@ -105,8 +105,18 @@ typedef struct {
   /* mode 1 */
   int32_t Gh, Gw, ws, q_stride;
   const void* pad_k; const void* pad_v; /* f16 [H*hd] or NULL (zeros) */
+  /* decomposed relative-position bias of SAM v1's ImageEncoderViT (TF sam :761-801): rel f16 [B*H*Tq][2*rel_S] from
+   * lmx_k_relpos_tables; score(q, key (ky,kx)) += rel[q][ky] + rel[q][rel_S + kx], key t -> (t / rel_S, t % rel_S).
+   * NULL = no bias.  Requires Tk == rel_S*rel_S and q_stride 1. */
+  const void* rel; int32_t rel_S;
 } lmx_attn_desc;
 int lmx_k_attention(const lmx_attn_desc* d, lmx_stream_t stream);
+/* rel[(b*H+h)*T + t][j]      = sum_c q[b,t,h,c] * rel_pos_h[ty - j + S-1][c]        (j < S)
+ * rel[(b*H+h)*T + t][S + j]  = sum_c q[b,t,h,c] * rel_pos_w[tx - j + S-1][c]        (t = ty*S + tx, T = S*S)
+ * q addressed with the attention geometry of `d` (mode 0 or window mode; d->Q, ldq, B, H, Tq, hd, mode, Gh, Gw, ws used),
+ * rel_pos_h / rel_pos_w f32 [2S-1][hd] (get_rel_pos without interpolation: q_size == k_size), out f16. */
+int lmx_k_relpos_tables(const lmx_attn_desc* d, const float* rel_pos_h, const float* rel_pos_w, int S, void* out,
+                        lmx_stream_t stream);
 
 /* ---- DINOv3 RoPE on the patch tokens of Q and K, in place (TF dinov3_vit :238-268) ------------------
  * x[b, t, h, :] for t >= n_prefix is rotated: x' = x*cos + rotate_half(x)*sin with cos/sin f32 [T-n_prefix][hd].

@@ -171,3 +171,67 @@ def test_mask_decoder_matches_oracle(cuda):
         ys, xs = torch.nonzero(mk[i], as_tuple=True)
         assert st[i, 0] == len(ys) and st[i, 1] == int(xs.sum()) and st[i, 2] == int(ys.sum())
         assert (st[i, 3], st[i, 4], st[i, 5], st[i, 6]) == (int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max()))
+
+
+def test_attention_relpos_bias(cuda):
+    """Decomposed relative-position bias (SAM v1): global 16x16 grid and 14x14 windows with zero-padded keys."""
+    from lmx import kernels as K
+
+    heads, hd = 2, 64
+    D = heads * hd
+    for (n, G, ws) in [(2, 16, 0), (1, 20, 14)]:
+        S = ws or G
+        rows = n * G * G
+        qkv = _rand((rows, 3 * D), 70, 1.0).half()
+        bias = _rand((3 * D,), 71, 0.3).half()
+        rh, rw = _rand((2 * S - 1, hd), 72, 0.3), _rand((2 * S - 1, hd), 73, 0.3)
+        x = qkv.float().view(n, G, G, 3, heads, hd)
+        if ws:
+            pad = (-G) % ws
+            full = bias.float().view(1, 1, 1, 3, heads, hd).expand(n, G + pad, G + pad, 3, heads, hd).clone()
+            full[:, :G, :G] = x
+            Gp = G + pad
+            win = full.view(n, Gp // ws, ws, Gp // ws, ws, 3, heads, hd).permute(0, 1, 3, 2, 4, 5, 6, 7).reshape(-1, ws * ws, 3, heads, hd)
+        else:
+            win = x.reshape(n, G * G, 3, heads, hd)
+        q, k, v = (win[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # [B, heads, T, hd]
+        idx = (torch.arange(S)[:, None] - torch.arange(S)[None, :]) + S - 1
+        rq = q.reshape(-1, heads, S, S, hd)
+        rel = (torch.einsum("bnhwc,hkc->bnhwk", rq, rh[idx])[..., :, None] + torch.einsum("bnhwc,wkc->bnhwk", rq, rw[idx])[..., None, :])
+        a = (q * hd ** -0.5) @ k.transpose(-1, -2) + rel.reshape(q.shape[0], heads, S * S, S * S)
+        o = (torch.softmax(a, -1) @ v).permute(0, 2, 1, 3).reshape(-1, S * S, D)
+        if ws:
+            o = o.view(n, Gp // ws, Gp // ws, ws, ws, D).permute(0, 1, 3, 2, 4, 5).reshape(n, Gp, Gp, D)[:, :G, :G]
+        ref = o.reshape(rows, D)
+        d = qkv.to(cuda)
+        bd = bias.to(cuda)
+        out = torch.zeros((rows, D), dtype=torch.float16, device=cuda)
+        if ws:
+            nW = (Gp // ws) ** 2
+            K.attention(d[:, :D], d[:, D:2 * D], d[:, 2 * D:], out, n * nW, heads, ws * ws, ws * ws, hd, hd ** -0.5,
+                        window=dict(Gh=G, Gw=G, ws=ws, q_stride=1), pad_k=bd[D:2 * D], pad_v=bd[2 * D:],
+                        rel_pos=(rh.to(cuda), rw.to(cuda)))
+        else:
+            K.attention(d[:, :D], d[:, D:2 * D], d[:, 2 * D:], out, n, heads, G * G, G * G, hd, hd ** -0.5,
+                        rel_pos=(rh.to(cuda), rw.to(cuda)))
+        err = float((out.float().cpu() - ref).abs().max())
+        assert err < 6e-3, f"rel-pos attention G={G} ws={ws}: max err {err}"
+
+
+def test_sam_vit_encoder_matches_oracle(cuda):
+    """SAM v1 ImageEncoderViT (reference code path for sam_vit_* checkpoints): small config, windowed + global layers."""
+    from lmx import sam, synth, weights
+    from oracle import preprocess as OP
+    from oracle import sam_vit as OV
+
+    cfg = sam.SamVitConfig(hidden=128, layers=3, heads=2, mlp=256, global_idx=(1,), window=14, image=512)
+    sd = weights.synth_state_dict(sam.vit_param_spec(cfg), seed=61)
+    frames = np.stack([synth.synth_frame(15, i) for i in (2, 33)], 0)
+    pv = torch.from_numpy(np.stack([OP.sam_pixel_values(f, cfg.image) for f in frames], 0))
+    with torch.no_grad():
+        ref = OV.encoder_forward(cfg, sd, pv).permute(0, 2, 3, 1)
+    out = sam.SamVitEncoder(cfg, sd, cuda).encode(torch.from_numpy(frames).to(cuda))["fpn"][2]
+    torch.cuda.synchronize()
+    rel, cos = _rel(out.float().cpu(), ref)
+    print("sam vit small: rel", rel, "cos", cos)
+    assert rel < 1e-2 and cos > 1 - 1e-4

@@ -66,7 +66,8 @@ __device__ __forceinline__ half4_t lds_tr_read(const half_t* p) {
 
 // QB: 16-query blocks per wave.  ONES: head dim <= 56, so V's (zero) column 63 is set to 1 and the PV MFMA itself
 // accumulates the softmax normaliser in O[:,63] — no row-sum instructions at all.
-template <int QB, bool ONES>
+// REL: SAM v1 decomposed relative-position bias read from the per-query tables of relpos_tables_kernel.
+template <int QB, bool ONES, bool REL>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, const Geo geo, const int nQT) {
   __shared__ __attribute__((aligned(16))) half_t Ks[2][64 * 64];
   __shared__ __attribute__((aligned(16))) half_t Vs[2][64 * 64];  // row-major [key][d], same swizzle as K
@@ -104,6 +105,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
       const half8_t qv = *reinterpret_cast<const half8_t*>(Q + (ok ? qrow[qb] * p.ldq + (int64_t)h * hd + d : 0));
       qf[qb][ks] = ok ? qv : zero8;
     }
+  }
+
+  // REL: this lane's query row of the bias table (2*rel_S halfs): [0,S) by key row, [S,2S) by key column
+  const half_t* relq[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int tq = q_base + qb * 16 + fr;
+    relq[qb] = REL ? reinterpret_cast<const half_t*>(p.rel) + (((int64_t)b * p.H + h) * p.Tq + (tq < p.Tq ? tq : 0)) * (2 * p.rel_S)
+                   : nullptr;
   }
 
   f32x4 oacc[QB][4];
@@ -169,7 +179,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
     }
   };
 
-  const float sl2 = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*sl2)
+  // exp(x*scale) = exp2(x*sl2); with REL the scores are first brought to natural units (s*scale + bias)
+  const float sl2 = REL ? 1.44269504088896340736f : p.scale * 1.44269504088896340736f;
   const int ntile = (p.Tk + 63) / 64;
   // transposed-read addressing of the V fragment: lane (q4 = (lane&15)>>2, p4 = lane&3) of a 16-lane group points at
   // row key0+q4, columns 16*db + 4*p4 .. +3
@@ -207,6 +218,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
     half8_t pf[QB][2];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
+      if (REL) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = t0 + kb * 16 + fg * 4 + r;
+            key = key < p.Tk ? key : 0;
+            const int ky = key / p.rel_S, kx = key - ky * p.rel_S;
+            const float bias = (float)relq[qb][ky] + (float)relq[qb][p.rel_S + kx];
+            sacc[qb][kb][r] = fmaf(sacc[qb][kb][r], p.scale, bias);
+          }
+      }
       if (MASK) {  // only the last tile can hold keys >= Tk
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -292,7 +315,75 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
   }
 }
 
+
+// thread = one (b, h, t): q row in registers, 2S dot products against the relative-position rows (L1/L2 resident).
+__global__ __launch_bounds__(256) void relpos_tables_kernel(const lmx_attn_desc p, const Geo geo, const float* __restrict__ rh,
+                                                            const float* __restrict__ rw, int S, half_t* __restrict__ out) {
+  const int64_t total = (int64_t)p.B * p.H * p.Tq;
+  const int hd = p.hd;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % p.Tq);
+    const int64_t bh = i / p.Tq;
+    const int h = (int)(bh % p.H);
+    const int b = (int)(bh / p.H);
+    const int64_t row = query_row(geo, b, t);
+    half_t* o = out + i * (2 * S);
+    if (row < 0) {  // padded query of a window: its attention output is discarded
+      for (int j = 0; j < 2 * S; ++j) o[j] = (half_t)0.f;
+      continue;
+    }
+    const half_t* q = reinterpret_cast<const half_t*>(p.Q) + row * p.ldq + (int64_t)h * hd;
+    float qv[64];
+#pragma unroll
+    for (int c = 0; c < 64; c += 8) {
+      if (c < hd) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(q + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[c + e] = (float)v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[c + e] = 0.f;
+      }
+    }
+    const int ty = t / S, tx = t - ty * S;
+    for (int j = 0; j < S; ++j) {
+      const float* r1 = rh + (int64_t)(ty - j + S - 1) * hd;
+      const float* r2 = rw + (int64_t)(tx - j + S - 1) * hd;
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 64; ++c) {
+        if (c < hd) {
+          a1 = fmaf(qv[c], r1[c], a1);
+          a2 = fmaf(qv[c], r2[c], a2);
+        }
+      }
+      o[j] = (half_t)a1;
+      o[S + j] = (half_t)a2;
+    }
+  }
+}
+
 }  // namespace
+
+static int build_geo(const lmx_attn_desc& d, Geo& g);
+
+extern "C" int lmx_k_relpos_tables(const lmx_attn_desc* dp, const float* rel_pos_h, const float* rel_pos_w, int S, void* out,
+                                   lmx_stream_t stream) {
+  LMX_REQUIRE(dp && rel_pos_h && rel_pos_w && out, "lmx_k_relpos_tables: null pointer");
+  const lmx_attn_desc& d = *dp;
+  LMX_REQUIRE(d.Q && d.B > 0 && d.H > 0 && d.Tq > 0 && d.hd % 8 == 0 && d.hd <= 64 && d.ldq % 8 == 0 && aligned16(d.Q),
+              "lmx_k_relpos_tables: descriptor");
+  LMX_REQUIRE(S > 0 && S * S == d.Tq, "lmx_k_relpos_tables: S=%d vs Tq=%d", S, d.Tq);
+  Geo g{};
+  const int rc = build_geo(d, g);
+  if (rc) return rc;
+  const int64_t total = (int64_t)d.B * d.H * d.Tq;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(relpos_tables_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d, g,
+                     rel_pos_h, rel_pos_w, S, reinterpret_cast<half_t*>(out));
+  return lmx_launch_check("relpos_tables_kernel");
+}
 
 extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   LMX_REQUIRE(dp != nullptr, "lmx_k_attention: null descriptor");
@@ -304,6 +395,37 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   LMX_REQUIRE(aligned16(d.Q) && aligned16(d.K) && aligned16(d.V) && ((((uintptr_t)d.O) & 7) == 0),
               "lmx_k_attention: alignment");
   Geo g{};
+  {
+    const int rc = build_geo(d, g);
+    if (rc) return rc;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+  const bool big = d.Tq > 64;
+  const int qtile = big ? 128 : 64;
+  const int nQT = (d.Tq + qtile - 1) / qtile;
+  const int64_t nblk = (int64_t)d.B * d.H * nQT;
+  LMX_REQUIRE(nblk < (1ll << 31), "lmx_k_attention: grid too large");
+  const bool ones = d.hd <= 56;
+  if (d.rel) {
+    LMX_REQUIRE(d.rel_S > 0 && d.rel_S * d.rel_S == d.Tk && d.Tq == d.Tk, "lmx_k_attention: rel_S=%d does not match Tq=%d Tk=%d",
+                d.rel_S, d.Tq, d.Tk);
+    if (big)
+      hipLaunchKernelGGL((attn_kernel<2, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    else
+      hipLaunchKernelGGL((attn_kernel<1, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  } else if (big && ones)
+    hipLaunchKernelGGL((attn_kernel<2, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  else if (big)
+    hipLaunchKernelGGL((attn_kernel<2, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  else if (ones)
+    hipLaunchKernelGGL((attn_kernel<1, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  else
+    hipLaunchKernelGGL((attn_kernel<1, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  return lmx_launch_check("attn_kernel");
+}
+
+static int build_geo(const lmx_attn_desc& d, Geo& g) {
   g.mode = d.mode;
   g.Tq = d.Tq;
   g.Tk = d.Tk;
@@ -328,21 +450,5 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   } else {
     LMX_REQUIRE(d.mode == 0, "lmx_k_attention: bad mode %d", d.mode);
   }
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-
-  const bool big = d.Tq > 64;
-  const int qtile = big ? 128 : 64;
-  const int nQT = (d.Tq + qtile - 1) / qtile;
-  const int64_t nblk = (int64_t)d.B * d.H * nQT;
-  LMX_REQUIRE(nblk < (1ll << 31), "lmx_k_attention: grid too large");
-  const bool ones = d.hd <= 56;
-  if (big && ones)
-    hipLaunchKernelGGL((attn_kernel<2, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
-  else if (big)
-    hipLaunchKernelGGL((attn_kernel<2, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
-  else if (ones)
-    hipLaunchKernelGGL((attn_kernel<1, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
-  else
-    hipLaunchKernelGGL((attn_kernel<1, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
-  return lmx_launch_check("attn_kernel");
+  return LMX_OK;
 }

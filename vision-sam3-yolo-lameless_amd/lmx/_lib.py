@@ -33,6 +33,7 @@ class AttnDesc(C.Structure):
         ("scale", C.c_float), ("mode", C.c_int32),
         ("Gh", C.c_int32), ("Gw", C.c_int32), ("ws", C.c_int32), ("q_stride", C.c_int32),
         ("pad_k", C.c_void_p), ("pad_v", C.c_void_p),
+        ("rel", C.c_void_p), ("rel_S", C.c_int32),
     ]
 
 
@@ -45,6 +46,7 @@ SIGNATURES = {
     "lmx_k_gemm": (_I, [C.POINTER(GemmDesc), _VP]),
     "lmx_k_layernorm": (_I, [_VP, _I, _I64, _VP, _VP, _VP, _I, _I64, _I, _I, _F, _I, _VP]),
     "lmx_k_attention": (_I, [C.POINTER(AttnDesc), _VP]),
+    "lmx_k_relpos_tables": (_I, [C.POINTER(AttnDesc), _VP, _VP, _I, _VP, _VP]),
     "lmx_k_rope": (_I, [_VP, _I64, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "lmx_k_pil_resize_h": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _I, _I, _VP]),
     "lmx_k_pil_resize_v": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _I, _VP]),

@@ -176,10 +176,7 @@ def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16, act=ACT_NO
     return out
 
 
-def attention(q, k, v, out, B, H, Tq, Tk, hd, scale, window=None, pad_k=None, pad_v=None):
-    """q/k/v/out: 2-D token-row views [rows, >=H*hd] (row stride = ld).  window = None (flat: row = b*T + t) or
-    dict(Gh, Gw, ws, q_stride) for in-place window addressing on the token grid."""
-    _dev(q, k, v, out, pad_k, pad_v)
+def _attn_desc(q, k, v, out, B, H, Tq, Tk, hd, scale, window, pad_k, pad_v):
     d = AttnDesc()
     d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
@@ -195,6 +192,25 @@ def attention(q, k, v, out, B, H, Tq, Tk, hd, scale, window=None, pad_k=None, pa
         d.Gh, d.Gw, d.ws, d.q_stride = window["Gh"], window["Gw"], window["ws"], window.get("q_stride", 1)
         d.pad_k = pad_k.data_ptr() if pad_k is not None else None
         d.pad_v = pad_v.data_ptr() if pad_v is not None else None
+    return d
+
+
+def attention(q, k, v, out, B, H, Tq, Tk, hd, scale, window=None, pad_k=None, pad_v=None, rel_pos=None):
+    """q/k/v/out: 2-D token-row views [rows, >=H*hd] (row stride = ld).  window = None (flat: row = b*T + t) or
+    dict(Gh, Gw, ws, q_stride) for in-place window addressing on the token grid.
+    rel_pos = (rel_pos_h, rel_pos_w) f32 [2S-1, hd] adds SAM v1's decomposed relative-position bias (S*S == Tk)."""
+    _dev(q, k, v, out, pad_k, pad_v)
+    d = _attn_desc(q, k, v, out, B, H, Tq, Tk, hd, scale, window, pad_k, pad_v)
+    keep = None
+    if rel_pos is not None:
+        rh, rw = rel_pos
+        _dev(rh, rw)
+        S = (rh.shape[0] + 1) // 2
+        if S * S != Tk or Tq != Tk or rh.dtype != torch.float32 or tuple(rh.shape) != (2 * S - 1, hd) or rh.shape != rw.shape:
+            raise LmxError("attention: rel_pos tables must be float32 [2S-1, hd] with S*S == Tq == Tk")
+        keep = torch.empty((B * H * Tq, 2 * S), dtype=torch.float16, device=q.device)
+        check(_lib.load().lmx_k_relpos_tables(C.byref(d), _ptr(rh), _ptr(rw), S, _ptr(keep), _stream()), "lmx_k_relpos_tables")
+        d.rel, d.rel_S = keep.data_ptr(), S
     check(_lib.load().lmx_k_attention(C.byref(d), _stream()), "lmx_k_attention")
     return out
 

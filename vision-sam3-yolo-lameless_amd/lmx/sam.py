@@ -258,3 +258,151 @@ class HieraEncoder:
         out = self.encode_patches(patches, frames.shape[0])
         out["resized"] = img
         return out
+
+
+# ======================================================================================================================
+# SAM v1 ImageEncoderViT — what `sam_model_registry["vit_b"|"vit_l"]` builds in services/sam3-pipeline/app/main.py:58-65
+# (SURVEY.md Appendix A.2).  vit_h has head dim 80 (> 64): not supported by the attention kernel yet.
+# ======================================================================================================================
+@dataclass
+class SamVitConfig:
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    mlp: int = 3072
+    global_idx: tuple = (2, 5, 8, 11)
+    window: int = 14
+    patch: int = 16
+    image: int = 1024
+    out_ch: int = 256
+    eps: float = 1e-6
+
+    @property
+    def grid(self):
+        return self.image // self.patch
+
+
+def sam_vit_b():
+    return SamVitConfig()
+
+
+def sam_vit_l():
+    return SamVitConfig(hidden=1024, layers=24, heads=16, mlp=4096, global_idx=(5, 11, 17, 23))
+
+
+def vit_param_spec(cfg):
+    """Ordered {transformers SamModel `vision_encoder.*` parameter name: (shape, init kind)}."""
+    D, hd, g = cfg.hidden, cfg.hidden // cfg.heads, cfg.grid
+    s = {"vision_encoder.pos_embed": ((1, g, g, D), "tok"),
+         "vision_encoder.patch_embed.projection.weight": ((D, 3, cfg.patch, cfg.patch), "w"),
+         "vision_encoder.patch_embed.projection.bias": ((D,), "b")}
+    for i in range(cfg.layers):
+        p = f"vision_encoder.layers.{i}."
+        S = g if i in cfg.global_idx else cfg.window
+        s[p + "layer_norm1.weight"] = ((D,), "g")
+        s[p + "layer_norm1.bias"] = ((D,), "b")
+        s[p + "attn.rel_pos_h"] = ((2 * S - 1, hd), "b")
+        s[p + "attn.rel_pos_w"] = ((2 * S - 1, hd), "b")
+        s[p + "attn.qkv.weight"] = ((3 * D, D), "w")
+        s[p + "attn.qkv.bias"] = ((3 * D,), "b")
+        s[p + "attn.proj.weight"] = ((D, D), "w")
+        s[p + "attn.proj.bias"] = ((D,), "b")
+        s[p + "layer_norm2.weight"] = ((D,), "g")
+        s[p + "layer_norm2.bias"] = ((D,), "b")
+        s[p + "mlp.lin1.weight"] = ((cfg.mlp, D), "w")
+        s[p + "mlp.lin1.bias"] = ((cfg.mlp,), "b")
+        s[p + "mlp.lin2.weight"] = ((D, cfg.mlp), "w")
+        s[p + "mlp.lin2.bias"] = ((D,), "b")
+    s["vision_encoder.neck.conv1.weight"] = ((cfg.out_ch, D, 1, 1), "w")
+    s["vision_encoder.neck.layer_norm1.weight"] = ((cfg.out_ch,), "g")
+    s["vision_encoder.neck.layer_norm1.bias"] = ((cfg.out_ch,), "b")
+    s["vision_encoder.neck.conv2.weight"] = ((cfg.out_ch, cfg.out_ch, 3, 3), "w")
+    s["vision_encoder.neck.layer_norm2.weight"] = ((cfg.out_ch,), "g")
+    s["vision_encoder.neck.layer_norm2.bias"] = ((cfg.out_ch,), "b")
+    return s
+
+
+class SamVitEncoder:
+    """Device-resident SAM v1 image encoder: patch-embed GEMM (+abs pos), windowed (14x14, zero-padded 64->70) and global
+    attention with decomposed relative-position bias, MLP, neck (1x1 -> LN2d -> 3x3 -> LN2d).  ``encode(frames)`` ->
+    dict(fpn=[None, None, embedding f16 [n,64,64,256]], resized=...) — same shape contract as HieraEncoder for the decoder."""
+
+    def __init__(self, cfg, state_dict, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        dev = self.device
+        sd = state_dict
+        D, P = cfg.hidden, cfg.patch
+
+        def t32(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+        def t16(a):
+            return t32(a).to(torch.float16).contiguous()
+
+        w = np.transpose(sd["vision_encoder.patch_embed.projection.weight"], (0, 2, 3, 1)).reshape(D, P * P * 3)
+        self.k_pad = P * P * 3  # 768: already a multiple of 8
+        self.pe_w, self.pe_b = t16(w), t32(sd["vision_encoder.patch_embed.projection.bias"])
+        self.pos = t32(sd["vision_encoder.pos_embed"].reshape(cfg.grid * cfg.grid, D))
+        self.layers = []
+        for i in range(cfg.layers):
+            p = f"vision_encoder.layers.{i}."
+            qb = sd[p + "attn.qkv.bias"]
+            self.layers.append(dict(
+                glob=i in cfg.global_idx,
+                g1=t32(sd[p + "layer_norm1.weight"]), b1=t32(sd[p + "layer_norm1.bias"]),
+                wqkv=t16(sd[p + "attn.qkv.weight"]), bqkv=t32(qb), padkv=t16(qb),
+                rh=t32(sd[p + "attn.rel_pos_h"]), rw=t32(sd[p + "attn.rel_pos_w"]),
+                wo=t16(sd[p + "attn.proj.weight"]), bo=t32(sd[p + "attn.proj.bias"]),
+                g2=t32(sd[p + "layer_norm2.weight"]), b2=t32(sd[p + "layer_norm2.bias"]),
+                w1=t16(sd[p + "mlp.lin1.weight"]), bb1=t32(sd[p + "mlp.lin1.bias"]),
+                w2=t16(sd[p + "mlp.lin2.weight"]), bb2=t32(sd[p + "mlp.lin2.bias"])))
+        self.n1_w = t16(sd["vision_encoder.neck.conv1.weight"][:, :, 0, 0])
+        self.n1_ln = (t32(sd["vision_encoder.neck.layer_norm1.weight"]), t32(sd["vision_encoder.neck.layer_norm1.bias"]))
+        c2 = sd["vision_encoder.neck.conv2.weight"]
+        self.n2_w = t16(np.transpose(c2, (0, 2, 3, 1)).reshape(c2.shape[0], -1))
+        self.n2_ln = (t32(sd["vision_encoder.neck.layer_norm2.weight"]), t32(sd["vision_encoder.neck.layer_norm2.bias"]))
+        self.lut = t32(sam_norm_lut())
+        self._tabs = {}
+
+    _tables = HieraEncoder._tables
+
+    def preprocess(self, frames):
+        n, h, w, _ = frames.shape
+        nh, nw, th, tv = self._tables(h, w)
+        img = K.pil_resize(frames, nw, nh, th, tv, swap_rb=False)
+        S, P = self.cfg.image, self.cfg.patch
+        return img, K.im2col_u8(img, self.lut, S, S, P, P, P, 0, self.k_pad)
+
+    def embed(self, patches, n):
+        cfg = self.cfg
+        g, D, H = cfg.grid, cfg.hidden, cfg.heads
+        hd = D // H
+        rows = n * g * g
+        x = K.gemm(patches, self.pe_w, bias=self.pe_b, res=self.pos, res_rows=g * g, out_dtype=torch.float32)
+        for L in self.layers:
+            h = K.layernorm(x, L["g1"], L["b1"], cfg.eps)
+            qkv = K.gemm(h, L["wqkv"], bias=L["bqkv"])
+            q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+            a = torch.empty((rows, D), dtype=torch.float16, device=x.device)
+            if L["glob"]:
+                K.attention(q, k, v, a, n, H, g * g, g * g, hd, hd ** -0.5, rel_pos=(L["rh"], L["rw"]))
+            else:
+                ws = cfg.window
+                nW = (-(-g // ws)) ** 2
+                K.attention(q, k, v, a, n * nW, H, ws * ws, ws * ws, hd, hd ** -0.5, window=dict(Gh=g, Gw=g, ws=ws, q_stride=1),
+                            pad_k=L["padkv"][D:2 * D], pad_v=L["padkv"][2 * D:], rel_pos=(L["rh"], L["rw"]))
+            K.gemm(a, L["wo"], bias=L["bo"], res=x, out=x)
+            h2 = K.layernorm(x, L["g2"], L["b2"], cfg.eps)
+            u = K.gemm(h2, L["w1"], bias=L["bb1"], act=K.ACT_GELU)
+            K.gemm(u, L["w2"], bias=L["bb2"], res=x, out=x)
+        # neck: 1x1 (no bias) -> LayerNorm2d -> 3x3 (no bias) -> LayerNorm2d
+        y = K.gemm(K.cast_f16(x), self.n1_w, out_dtype=torch.float32)
+        y = K.layernorm(y, *self.n1_ln, 1e-6)
+        y = K.conv3x3(y.view(n, g, g, cfg.out_ch), self.n2_w, bias=None, act=K.ACT_NONE)
+        y = K.layernorm(y.view(rows, cfg.out_ch), *self.n2_ln, 1e-6)
+        return y.view(n, g, g, cfg.out_ch)
+
+    def encode(self, frames):
+        img, patches = self.preprocess(frames)
+        return dict(fpn=[None, None, self.embed(patches, frames.shape[0])], resized=img)

@@ -132,7 +132,8 @@ class SAM3Pipeline:
 
 
 class HieraSegmenter:
-    """Adapter giving HieraEncoder + MaskDecoder the `segment(frames, boxes)` surface the service needs."""
+    """Adapter giving an image encoder (HieraEncoder, or SamVitEncoder for `sam_vit_b/l` checkpoints: main.py:58-65) +
+    MaskDecoder the `segment(frames, boxes)` surface the service needs."""
 
     def __init__(self, encoder, decoder):
         self.encoder, self.decoder = encoder, decoder
@@ -145,3 +146,6 @@ class HieraSegmenter:
         enc = self.encoder.encode(frames)
         e2 = enc["fpn"][2]
         return self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes, (h, w), sam.resize_longest_side(h, w, self.encoder.cfg.image))["mask"]
+
+
+SamSegmenter = HieraSegmenter  # the adapter only relies on encode(...)["fpn"][2] being the [n,64,64,256] embedding
