@@ -22,8 +22,6 @@
 // instantiated from another template — the library then fails to load with an undefined symbol)
 namespace lmx_gemm2 {
 
-constexpr int BN = 128;
-
 // Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7): rcp + exp + 6 fma instead of libm's branchy erff in the epilogue.
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
@@ -58,8 +56,10 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst_l
 // hipcc drop the HOST stub of the enclosing kernel template without a diagnostic)
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 3 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal for this count");
+  static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal for this count");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -67,13 +67,13 @@ __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
-// BM x 128 x BK tile, NSTAGE-slot LDS ring, (BM/64) x 2 waves of 64 x 64 outputs.
+// BM x BN x BK tile, NSTAGE-slot LDS ring, (BM/64) x (BN/64) waves of 64 x 64 outputs.
 // AMODE 1: A is generated from an NHWC image batch (3x3, pad 1, stride 1|2; gemm.hip's a_mode 1) — requires Cin % BK == 0
 // so that a k-tile lies inside one filter tap: the tap (ky,kx) is then wave-uniform per k-tile and a lane only adds a
 // constant to its pixel offset; out-of-image taps take the out-of-range offset and the descriptor returns zeros.
-template <int OUT_DT, int BM, int BK, int NSTAGE, int AMODE>
-__global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
-  constexpr int NWAVE = BM / 32;
+template <int OUT_DT, int BM, int BN, int BK, int NSTAGE, int AMODE>
+__global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p) {
+  constexpr int NWAVE = (BM / 64) * (BN / 64);
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int A_INSTR = BM * BK * 2 / 1024 / NWAVE;  // LDS-DMA wave-instructions (1 KB each) per wave per k-tile
   constexpr int W_INSTR = BN * BK * 2 / 1024 / NWAVE;
@@ -185,8 +185,12 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
     constexpr int PT = A_INSTR + W_INSTR;
     const int left = nk - 1 - kt;
     const int younger = left < LA - 1 ? left : LA - 1;
-    if (younger >= 2)
-      wait_vmcnt<2 * PT>();
+    if (LA >= 5 && younger >= 4)
+      wait_vmcnt<(LA >= 5 ? 4 : 0) * PT>();
+    else if (LA >= 4 && younger == 3)
+      wait_vmcnt<(LA >= 4 ? 3 : 0) * PT>();
+    else if (LA >= 3 && younger == 2)
+      wait_vmcnt<(LA >= 3 ? 2 : 0) * PT>();
     else if (younger == 1)
       wait_vmcnt<PT>();
     else
@@ -297,22 +301,22 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const lmx_gemm_desc p) {
   }
 }
 
-template <int BM, int BK, int NSTAGE, int AMODE>
+template <int BM, int BN, int BK, int NSTAGE, int AMODE>
 int launch2(const lmx_gemm_desc& d, hipStream_t st) {
   const int MT = (d.M + BM - 1) / BM, NT = (d.N + BN - 1) / BN;
-  const size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;
+  const size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;  // >= NWAVE * 4608 B of epilogue staging for every variant
   static bool attr_set = false;
   if (!attr_set) {
-    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F16, BM, BK, NSTAGE, AMODE>),
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F32, BM, BK, NSTAGE, AMODE>),
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
   if (d.out_dtype == LMX_F16)
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BK, NSTAGE, AMODE>), dim3(MT * NT), dim3(BM * 2), smem, st, d);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE>), dim3(MT * NT), dim3(BM * BN / 64), smem, st, d);
   else
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BK, NSTAGE, AMODE>), dim3(MT * NT), dim3(BM * 2), smem, st, d);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE>), dim3(MT * NT), dim3(BM * BN / 64), smem, st, d);
   return lmx_launch_check("gemm2_kernel");
 }
 
@@ -328,15 +332,18 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     const char* e = getenv("LMX_GEMM2_VARIANT");
     variant = e ? e[0] : 0;
   }
-  if (d.a_mode == 1) return launch2<256, 32, 3, 1>(d, st);  // 3x3 convolution, Cin % 32 == 0 (checked by the caller)
+  if (d.a_mode == 1) return launch2<256, 128, 32, 3, 1>(d, st);  // 3x3 convolution, Cin % 32 == 0 (checked by the caller)
   switch (variant) {
-    case 'A': return launch2<256, 64, 3, 0>(d, st);
-    case 'B': return launch2<128, 64, 2, 0>(d, st);
-    case 'C': return launch2<256, 32, 3, 0>(d, st);
-    case 'D': return launch2<256, 32, 2, 0>(d, st);
+    case 'A': return launch2<256, 128, 64, 3, 0>(d, st);
+    case 'B': return launch2<128, 128, 64, 2, 0>(d, st);
+    case 'C': return launch2<256, 128, 32, 3, 0>(d, st);
+    case 'D': return launch2<256, 128, 32, 2, 0>(d, st);
+    case 'E': return launch2<256, 256, 32, 3, 0>(d, st);  // 16 waves, 96 KB, 1 block/CU: half the L2->LDS bytes per flop
+    case 'F': return launch2<256, 256, 32, 4, 0>(d, st);  // ... 128 KB ring: three k-tiles in flight
+    case 'G': return launch2<256, 256, 32, 5, 0>(d, st);  // ... 160 KB ring: four k-tiles in flight
     default:
       // measured on the model shapes (profiles/r01_gemm_variants.txt): with K <= ~2k the per-tile prologue/epilogue
       // dominates and two co-resident blocks (C) hide it; long-K problems prefer the deeper 64-wide ring (A)
-      return d.K >= 3072 ? launch2<256, 64, 3, 0>(d, st) : launch2<256, 32, 3, 0>(d, st);
+      return d.K >= 3072 ? launch2<256, 128, 64, 3, 0>(d, st) : launch2<256, 128, 32, 3, 0>(d, st);
   }
 }
