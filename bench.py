@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=32, help="1080p frames per GPU per step")
+    ap.add_argument("--sam-chunk", type=int, default=32, help="frames per SAM encoder pass (bounds live activations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     args = ap.parse_args()
@@ -108,7 +109,7 @@ def main():
     frames = torch.from_numpy(host).to(dev)
 
     def step():
-        out = fx.step(frames)
+        out = fx.step(frames, sam_chunk=args.sam_chunk)
         return ldist.gather_frame_records(out) if world > 1 else out
 
     for i in range(args.warmup):

@@ -51,6 +51,27 @@ def main():
             print(f"gemm {M}x{N}x{K_} act{act} {'f32+res' if f32 else 'f16'}: {ms:.3f} ms  {2 * M * N * K_ / ms / 1e9:.1f} TFLOP/s",
                   flush=True)
         print(f"model-shape total {tot:.3f} ms", flush=True)
+    if "narrow" in which:
+        tot = 0.0
+        for (M, N, K_, act, f32) in [(1048576, 448, 112, 2, 0), (1048576, 112, 448, 0, 1), (1048576, 336, 112, 0, 0),
+                                     (1048576, 112, 112, 0, 1), (1048576, 672, 112, 0, 0), (262144, 896, 224, 2, 0),
+                                     (262144, 224, 896, 0, 1), (262144, 672, 224, 0, 0), (262144, 224, 224, 0, 1),
+                                     (65536, 448, 448, 0, 1), (65536, 1792, 448, 2, 0), (65536, 448, 1792, 0, 1)]:
+            a = torch.randn((M, K_), device=dev).half()
+            w = (torch.randn((N, K_), device=dev) * K_ ** -0.5).half()
+            b = torch.randn((N,), device=dev)
+            if f32:
+                out = torch.randn((M, N), device=dev, dtype=torch.float32)
+                ms = timeit(lambda: K.gemm(a, w, bias=b, act=act, res=out, out=out), iters=10)
+                nbytes = M * K_ * 2 + 2 * M * N * 4
+            else:
+                out = torch.empty((M, N), device=dev, dtype=torch.float16)
+                ms = timeit(lambda: K.gemm(a, w, bias=b, act=act, out=out), iters=10)
+                nbytes = M * K_ * 2 + M * N * 2
+            tot += ms
+            print(f"gemm {M}x{N}x{K_} act{act} {'f32+res' if f32 else 'f16'}: {ms:.3f} ms  {2 * M * N * K_ / ms / 1e9:.1f} TFLOP/s  "
+                  f"{nbytes / ms / 1e9:.2f} TB/s", flush=True)
+        print(f"narrow total {tot:.3f} ms", flush=True)
     if "attn" in which or "dino" in which:
         B, H, T, hd = 256, 16, 201, 64
         qkv = torch.randn((B * T, 3 * H * hd), device=dev).half()

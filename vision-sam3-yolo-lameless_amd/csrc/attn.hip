@@ -75,7 +75,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
 
-  int bid = blockIdx.x;
+  // XCD-aware bijective remap: the hardware deals consecutive workgroups round-robin over the 8 XCDs; give each XCD a
+  // contiguous range of work items instead, so the query tiles of one (image, head) share that XCD's L2 copy of K/V.
+  int bid;
+  {
+    const int n = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n >> 3, r = n & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int qt = bid % nQT;
   bid /= nQT;
   const int h = bid % p.H;

@@ -200,6 +200,9 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p) {
     const char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
     const half_t* as = reinterpret_cast<const half_t*>(st) + (wm * 64 + frow) * BK;
     const half_t* ws = reinterpret_cast<const half_t*>(st + BM * BK * 2) + (wn * 64 + frow) * BK;
+#ifdef LMX_DBG_NOMFMA
+    if (p.M < 0)  // development probe: keep the staging pipeline, drop fragment reads and MFMAs
+#endif
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       const int coff = (((ks << 2) + fq) ^ fsw) << 3;
@@ -224,6 +227,9 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p) {
   // 16-byte lane stores; the residual is read in the same coalesced shape.  bias / activation / LayerScale are applied
   // in registers on the way in.
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last k-tile
+#ifdef LMX_DBG_NOEPI
+  if (p.M > 0 && acc[0][0][0] != 12345.f) return;  // development probe: no epilogue
+#endif
   const int act = p.act;
   char* my = smem + wave * 4608;  // 32 rows x 144 B (f16) or 16 rows x 272 B (f32) per pass
   f32x4 bia[4], scl[4];
@@ -341,6 +347,8 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     case 'E': return launch2<256, 256, 32, 3, 0>(d, st);  // 16 waves, 96 KB, 1 block/CU: half the L2->LDS bytes per flop
     case 'F': return launch2<256, 256, 32, 4, 0>(d, st);  // ... 128 KB ring: three k-tiles in flight
     case 'G': return launch2<256, 256, 32, 5, 0>(d, st);  // ... 160 KB ring: four k-tiles in flight
+    case 'H': return launch2<128, 128, 32, 2, 0>(d, st);  // 4 waves, 32 KB: up to 4 blocks/CU for short-K (HBM-bound) shapes
+    case 'I': return launch2<128, 128, 32, 3, 0>(d, st);  // 4 waves, 48 KB: 3 blocks/CU
     default:
       // measured on the model shapes (profiles/r01_gemm_variants.txt): with K <= ~2k the per-tile prologue/epilogue
       // dominates and two co-resident blocks (C) hide it; long-K problems prefer the deeper 64-wide ring (A)

@@ -26,7 +26,7 @@ class FusedExtractor:
         dcfg = dino.dinov3_vitl16()
         self.dino = dino.DinoEmbedder(dcfg, weights.synth_state_dict(dino.param_spec(dcfg), weight_seeds[2]), self.device)
 
-    def step(self, frames, conf=0.5, sam_chunk=16):
+    def step(self, frames, conf=0.5, sam_chunk=32):
         """frames u8 [n,1080,1920,3] BGR on device -> dict of device tensors for every frame (dense schedule)."""
         n, h, w, _ = frames.shape
         boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf)
