@@ -142,6 +142,40 @@ def test_layernorm(cuda, rows, D):
     _close(got_h, F.layer_norm(x.half().float(), (D,), g, b, 1e-5), 2e-5, 2e-5, "layernorm f16 in")
 
 
+# ------------------------------------------------------------------------ fused LayerNorm + MLP (narrow widths)
+@pytest.mark.parametrize("rows,D", [(1, 112), (130, 112), (4099, 112), (63, 224), (2050, 224)])
+def test_ln_mlp_fused(cuda, rows, D):
+    """x += fc2(gelu(fc1(LN(x)))) in one kernel: against fp32 torch on the f16-rounded weights, and against the unfused
+    LN -> GEMM -> GEMM launches of the same library (same rounding points: only the accumulation order differs)."""
+    from lmx import kernels as Kk
+
+    x = _rand((rows, D), 70, 2.0) + 0.3
+    g, b = _rand((D,), 71) * 0.1 + 1, _rand((D,), 72) * 0.1
+    w1 = (_rand((4 * D, D), 73) * D ** -0.5).half()
+    w2 = (_rand((D, 4 * D), 74) * (4 * D) ** -0.5).half()
+    b1, b2 = _rand((4 * D,), 75) * 0.1, _rand((D,), 76) * 0.1
+    ref = x + F.linear(F.gelu(F.linear(F.layer_norm(x, (D,), g, b, 1e-6), w1.float(), b1)), w2.float(), b2)
+    dev = [t.to(cuda) for t in (g, b, w1, b1, w2, b2)]
+    got = Kk.ln_mlp(x.clone().to(cuda), *dev, 1e-6)
+    _close(got, ref, 6e-3, 3e-3, "fused ln_mlp vs fp32")
+    xu = x.clone().to(cuda)
+    h = Kk.layernorm(xu, dev[0], dev[1], 1e-6)
+    u = Kk.gemm(h, dev[2], bias=dev[3], act=Kk.ACT_GELU)
+    Kk.gemm(u, dev[4], bias=dev[5], res=xu, out=xu)
+    _close(got, xu, 2e-3, 1e-3, "fused ln_mlp vs unfused launches")
+
+
+def test_ln_mlp_rejects_other_widths(cuda):
+    from lmx import kernels as Kk
+    from lmx._lib import LmxError
+
+    D = 448
+    z = torch.zeros
+    with pytest.raises(LmxError):
+        Kk.ln_mlp(z((8, D), device=cuda), z(D, device=cuda), z(D, device=cuda), z((4 * D, D), device=cuda, dtype=torch.float16),
+                  z(4 * D, device=cuda), z((D, 4 * D), device=cuda, dtype=torch.float16), z(D, device=cuda), 1e-6)
+
+
 # ------------------------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, scale):
     w = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)

@@ -44,6 +44,61 @@ static inline int lmx_launch_check(const char* what) {
   return LMX_OK;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// erf-GELU for two values at once: gelu(v) = v * (0.5 + g(v)), g(v) = 0.5*erf(v/sqrt2) ~ vc * P(vc^2) with
+// vc = clamp(v, -4.5, 4.5) and P of degree 9 (weighted least-squares Chebyshev fit, evaluated in f32: |error| <= 3.4e-5
+// for every v, i.e. a tenth of the f16 rounding of an O(1) result; tools/fit_gelu.py reproduces the coefficients).
+// No transcendental (v_rcp / v_exp are quarter rate) and written on 2-vectors so the Horner chain is v_pk_fma_f32:
+// ~7.5 VALU issue slots per value against ~23 for the Abramowitz-Stegun erf it replaces.  At D = 112..448 the GELU of an
+// MLP otherwise costs more VALU time than its two GEMMs cost MFMA time.
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 v) {
+  f32x2 vc;
+  vc[0] = __builtin_amdgcn_fmed3f(v[0], -4.5f, 4.5f);
+  vc[1] = __builtin_amdgcn_fmed3f(v[1], -4.5f, 4.5f);
+  const f32x2 u = vc * vc;
+  f32x2 p = {-1.223331157e-12f, -1.223331157e-12f};
+  p = p * u + 1.524351007e-10f;
+  p = p * u + -8.481037793e-09f;
+  p = p * u + 2.798429583e-07f;
+  p = p * u + -6.151207192e-06f;
+  p = p * u + 9.615961466e-05f;
+  p = p * u + -1.114801972e-03f;
+  p = p * u + 9.814679350e-03f;
+  p = p * u + -6.632144717e-02f;
+  p = p * u + 3.988863025e-01f;
+  const f32x2 g = vc * p;
+  return v * g + 0.5f * v;
+}
+__device__ __forceinline__ float gelu_1(float v) {
+  const f32x2 r = gelu_pk(f32x2{v, v});
+  return r[0];
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// One LDS-DMA wave-instruction (buffer_load_dwordx4 ... lds): lane i's 16 bytes land at dst + 16*i.  Kept in a
+// NON-template function: inside a kernel template with dependent arguments the amdgcn builtin makes the HOST pass drop
+// the kernel's instantiation without a diagnostic (the .so then fails to load with an undefined __device_stub__).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst_lds, unsigned voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst_lds, 16, voffset, soffset, 0, 0);
+}
+
+// counted wait with a literal immediate per instantiation (an "n"-constrained template-dependent asm operand makes
+// hipcc drop the HOST stub of the enclosing kernel template without a diagnostic)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal for this count");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -22,49 +22,11 @@
 // instantiated from another template — the library then fails to load with an undefined symbol)
 namespace lmx_gemm2 {
 
-// Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7): rcp + exp + 6 fma instead of libm's branchy erff in the epilogue.
-__device__ __forceinline__ float fast_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
-  const float r = fmaf(-p, e, 1.0f);
-  return copysignf(r, x);
-}
-
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == LMX_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.44269504088896340736f));
-  if (act == LMX_ACT_GELU) return 0.5f * v * (1.0f + fast_erf(v * 0.70710678118654752440f));
+  if (act == LMX_ACT_GELU) return gelu_1(v);
   if (act == LMX_ACT_RELU) return fmaxf(v, 0.0f);
   return v;
-}
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// One LDS-DMA wave-instruction (buffer_load_dwordx4 ... lds): lane i's 16 bytes land at dst + 16*i.  Kept in a
-// NON-template function: inside a kernel template with dependent arguments the amdgcn builtin makes the HOST pass drop
-// the kernel's instantiation without a diagnostic (the .so then fails to load with an undefined __device_stub__).
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst_lds, unsigned voffset, int soffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst_lds, 16, voffset, soffset, 0, 0);
-}
-
-// counted wait with a literal immediate per instantiation (an "n"-constrained template-dependent asm operand makes
-// hipcc drop the HOST stub of the enclosing kernel template without a diagnostic)
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal for this count");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
 // BM x BN x BK tile, NSTAGE-slot LDS ring, (BM/64) x (BN/64) waves of 64 x 64 outputs.
@@ -249,7 +211,10 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4 v = acc[pass * 2 + ii][j] + bia[j];
-          if (act != LMX_ACT_NONE) {
+          if (act == LMX_ACT_GELU) {  // two values per v_pk_fma_f32 chain
+            const f32x2 g0 = gelu_pk(f32x2{v[0], v[1]}), g1 = gelu_pk(f32x2{v[2], v[3]});
+            v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+          } else if (act != LMX_ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
           }
@@ -282,7 +247,10 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4 v = acc[pass][j] + bia[j];
-        if (act != LMX_ACT_NONE) {
+        if (act == LMX_ACT_GELU) {
+          const f32x2 g0 = gelu_pk(f32x2{v[0], v[1]}), g1 = gelu_pk(f32x2{v[2], v[3]});
+          v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+        } else if (act != LMX_ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
         }

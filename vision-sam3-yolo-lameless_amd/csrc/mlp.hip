@@ -1,0 +1,274 @@
+// mlp.hip — fused LayerNorm -> fc1 -> GELU -> fc2 -> +residual for NARROW token widths (Hiera stages 1-2: D = 112, 224;
+// TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward: `hidden_states + mlp(layer_norm2(hidden_states))`).
+//
+// Why: at D <= 224 the unfused chain  LN kernel -> GEMM(D->4D, GELU) -> GEMM(4D->D, +res)  is HBM-bound on its
+// intermediates: per token it moves 4D (LN read) + 2D (LN write) + 2D + 8D (fc1) + 8D + 4D + 4D (fc2) = 32 D bytes, of
+// which only the f32 residual stream (4D read + 4D write) is algorithmic.  Here a workgroup keeps its tokens' 4D hidden
+// activations in registers: the structure is the flash-attention one (attn.hip) with W1 rows in the role of keys, W2
+// columns in the role of values and GELU in the role of the softmax:
+//     H^T[32 hidden][tokens] = W1c . LN(x)^T      (MFMA, A = W1 rows from LDS, B = the wave's normalised tokens, registers)
+//     P = f16(gelu(H^T + b1))                      (the accumulator layout IS the next B operand, k-slot permuted)
+//     O^T[D][tokens]        += W2c^T-slice . P     (MFMA, A = W2 rows from LDS read as two 8-byte pieces)
+// The weights (<= 800 KB, L2-resident) stream through a 4-slot LDS ring in 32-hidden-unit chunks by LDS-DMA
+// (buffer_load ... lds, no VGPR round trip), three chunks in flight, ONE raw s_barrier + counted s_waitcnt vmcnt per
+// chunk exactly as gemm2.hip.  (A first version staged through registers one chunk ahead: every chunk then waited a full
+// L2 latency for the loads issued at its own start — 6000 cycles per chunk against 480 cycles of MFMA.)
+// HBM traffic per token: 4D read (+ a second, L2-hot, read for the residual) + 4D write.
+#include "common.h"
+#include <stdlib.h>
+
+namespace lmx_mlp {
+
+constexpr int HC = 32;   // hidden units per chunk (one MFMA k-step of the second GEMM)
+
+// D: token width (multiple of 16, <= 256).  NW waves of QB 16-token blocks: a workgroup owns NW*16*QB tokens.
+// Every wave issues 4 LDS-DMA instructions (4 KB) per chunk: NW*4 KB = one ring slot = [W1 chunk | W2 chunk].
+// NST: LDS ring slots (NST-1 chunks in flight).  OCC: workgroups per CU the register budget must allow.
+template <int D, int QB, int NW, int NST, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __restrict__ x, int64_t ldx,
+                                                                          const float* __restrict__ gam,
+                                                                          const float* __restrict__ bet,
+                                                                          const half_t* __restrict__ w1,
+                                                                          const float* __restrict__ b1,
+                                                                          const half_t* __restrict__ w2,
+                                                                          const float* __restrict__ b2, int64_t rows, float eps) {
+  constexpr int KS = (D + 31) / 32;           // k-steps of the first GEMM
+  constexpr int DP = D <= 128 ? 128 : 256;    // halfs per LDS row of a W1 chunk (power of two: XOR swizzle stays in the row)
+  constexpr int DB = D / 16;                  // 16-wide output blocks
+  constexpr int NCH = 4 * D / HC;             // chunks
+  constexpr int W1_BYTES = HC * DP * 2;       // 8 KB | 16 KB
+  constexpr int W2_ROWS = DP;                 // W2 chunk rows padded to 128 | 256 (rows >= D read as zeros, never used)
+  constexpr int W2_BYTES = W2_ROWS * 64;      // 8 KB | 16 KB
+  constexpr int STAGE = W1_BYTES + W2_BYTES;
+  constexpr int PT = 4;                       // DMA instructions per wave per chunk
+  constexpr int LA = NST - 1;
+  static_assert(STAGE == NW * PT * 1024, "one ring slot = NW waves x 4 KB");
+  static_assert(W1_BYTES == (NW / 2) * PT * 1024, "the first half of the waves stages W1, the second half W2");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* b1s = reinterpret_cast<float*>(smem + NST * STAGE);  // fc1 bias, 4D floats
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- LDS-DMA plan.  An instruction writes 64 x 16 B linearly, so the swizzle goes on the per-lane SOURCE address;
+  // lanes whose piece does not exist (k-padding of W1, row padding of W2) take an out-of-range offset: the buffer
+  // descriptor's range check returns zeros.
+  const __amdgpu_buffer_rsrc_t w1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(w1), 0, 4 * D * D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(w2), 0, 4 * D * D * 2, 0x00020000);
+  const bool stage_w1 = wave < NW / 2;
+  const unsigned OOB = 0x80000000u;
+  unsigned voff[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    if (stage_w1) {
+      constexpr int CPR = DP / 8;                       // 16-byte pieces per LDS row: 16 | 32
+      const int i = wave * PT + t;                      // KB index inside the W1 chunk
+      const int row = i * (64 / CPR) + lane / CPR;      // 4 | 2 rows per instruction
+      const int lc = (lane % CPR) ^ (row & 15);         // logical piece stored at this physical slot
+      voff[t] = lc < D / 8 ? (unsigned)(row * D * 2 + lc * 16) : OOB;
+    } else {
+      const int i = (wave - NW / 2) * PT + t;           // KB index inside the W2 chunk: 16 rows of 64 B
+      const int row = i * 16 + (lane >> 2);
+      const int lc = (lane & 3) ^ ((row >> 2) & 3);
+      voff[t] = row < D ? (unsigned)(row * (4 * D) * 2 + lc * 16) : OOB;
+    }
+  }
+  auto issue = [&](int c, int slot) {
+    char* dst = smem + slot * STAGE + wave * (PT * 1024);  // waves NW/2.. land in the W2 half: W1_BYTES == NW/2 * 4 KB
+    const int soff = stage_w1 ? c * (HC * D * 2) : c * (HC * 2);
+#pragma unroll
+    for (int t = 0; t < PT; ++t) lds_dma16(stage_w1 ? w1_rs : w2_rs, dst + t * 1024, voff[t], soff);
+  };
+#pragma unroll
+  for (int c = 0; c < LA; ++c) issue(c, c);
+
+  for (int i = tid; i < 4 * D; i += NW * 64) b1s[i] = b1[i];
+
+  // ---- LayerNorm of this wave's tokens straight into MFMA B-operand fragments: lane (fr, fg) holds, for token fr of
+  // block qb, the 8 features 32*ks + 8*fg .. +7 of every k-step; a token's D features sit in the 4 lanes fr, fr+16, ..
+  const int64_t tok0 = (int64_t)blockIdx.x * (NW * 16 * QB) + wave * (16 * QB);
+  half8_t xn[QB][KS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int64_t t = tok0 + qb * 16 + fr;
+    const float* xr = x + (t < rows ? t : 0) * ldx;
+    // three passes over the (L1/L2-hot) row instead of holding its D/4 values per lane: keeps the prologue's register
+    // peak below the main loop's
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d = ks * 32 + fg * 8;
+      if (d < D) {  // D % 8 == 0: a lane's 8 features are all in or all out
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + d), b = *reinterpret_cast<const f32x4*>(xr + d + 4);
+        s += (a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3]);
+      }
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d = ks * 32 + fg * 8;
+      if (d < D) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + d) - mean, b = *reinterpret_cast<const f32x4*>(xr + d + 4) - mean;
+        q += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
+      }
+    }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / D) + eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d = ks * 32 + fg * 8;
+      const bool ok = d < D;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam + (ok ? d : 0)), g1 = *reinterpret_cast<const f32x4*>(gam + (ok ? d + 4 : 0));
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(bet + (ok ? d : 0)), c1 = *reinterpret_cast<const f32x4*>(bet + (ok ? d + 4 : 0));
+      const f32x4 va = *reinterpret_cast<const f32x4*>(xr + (ok ? d : 0)), vb = *reinterpret_cast<const f32x4*>(xr + (ok ? d + 4 : 0));
+      half8_t h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (half_t)(ok ? (va[e] - mean) * rstd * g0[e] + c0[e] : 0.f);
+        h[4 + e] = (half_t)(ok ? (vb[e] - mean) * rstd * g1[e] + c1[e] : 0.f);
+      }
+      xn[qb][ks] = h;
+    }
+  }
+
+  f32x4 oacc[QB][DB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int c = 0; c < NCH; ++c) {
+    // chunk c has landed once only this wave's DMAs of the (at most LA-1) younger chunks are outstanding; everything the
+    // prologue loaded from global memory is consumed by now, and nothing else is loaded from global memory inside the
+    // loop (the fc1 bias sits in LDS), so the count is exact
+    const int left = NCH - 1 - c;
+    if (LA >= 3 && left >= 2)
+      wait_vmcnt<(LA >= 3 ? 2 : 0) * PT>();
+    else if (left >= 1)
+      wait_vmcnt<PT>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // (also publishes b1s on the first pass)
+    if (c + LA < NCH) issue(c + LA, (c + LA) % NST);
+    const char* st = smem + (c % NST) * STAGE;
+    const half_t* W1c = reinterpret_cast<const half_t*>(st);
+    const char* W2c = st + W1_BYTES;
+
+    // fc1 bias of this lane's 8 hidden units: 32c + 16hb + 4fg + i; the MFMA chain adds it for free
+    f32x4 sacc[QB][2];
+    {
+      const f32x4 bia0 = *reinterpret_cast<const f32x4*>(b1s + c * HC + fg * 4);
+      const f32x4 bia1 = *reinterpret_cast<const f32x4*>(b1s + c * HC + 16 + fg * 4);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        sacc[qb][0] = bia0;
+        sacc[qb][1] = bia1;
+      }
+    }
+    // ---- H^T = W1c . LN(x)^T
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const int row = hb * 16 + fr;
+        const half8_t a = *reinterpret_cast<const half8_t*>(W1c + row * DP + (((ks * 4 + fg) ^ (row & 15)) << 3));
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][hb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[qb][ks], sacc[qb][hb], 0, 0, 0);
+      }
+    }
+    // ---- P = f16(gelu(H^T)): accumulator element i of block hb is hidden unit 16hb + 4fg + i of token fr — exactly
+    // k-slot 8fg + (4hb + i) of the next MFMA's B operand once W2's columns are read in the same permuted order
+    half8_t pf[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const f32x2 g0 = gelu_pk(f32x2{sacc[qb][hb][0], sacc[qb][hb][1]});
+        const f32x2 g1 = gelu_pk(f32x2{sacc[qb][hb][2], sacc[qb][hb][3]});
+        pf[qb][4 * hb + 0] = (half_t)g0[0];
+        pf[qb][4 * hb + 1] = (half_t)g0[1];
+        pf[qb][4 * hb + 2] = (half_t)g1[0];
+        pf[qb][4 * hb + 3] = (half_t)g1[1];
+      }
+    }
+    // ---- O^T += W2[:, chunk] . P.  W2 chunk row = 64 B = four 16-B pieces, piece p stored at p ^ ((row >> 2) & 3);
+    // the fragment is hidden units 4fg..4fg+3 (piece fg>>1) and 16+4fg..+3 (piece 2 + (fg>>1)), 8 bytes each
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int row = db * 16 + fr;
+      const int sw = (row >> 2) & 3;
+      const char* wr = W2c + row * 64 + (fg & 1) * 8;
+      const half4_t lo = *reinterpret_cast<const half4_t*>(wr + (((fg >> 1)) ^ sw) * 16);
+      const half4_t hi = *reinterpret_cast<const half4_t*>(wr + ((2 + (fg >> 1)) ^ sw) * 16);
+      const half8_t a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[qb], oacc[qb][db], 0, 0, 0);
+    }
+  }
+
+  // ---- x += O + b2.  Accumulator: token fr, features 16db + 4fg .. +3 (16 bytes per lane, 64 contiguous bytes per token)
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int64_t t = tok0 + qb * 16 + fr;
+    if (t < rows) {
+      float* xr = x + t * ldx;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const int d = db * 16 + fg * 4;
+        const f32x4 r = *reinterpret_cast<const f32x4*>(xr + d);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + d);
+        *reinterpret_cast<f32x4*>(xr + d) = oacc[qb][db] + bb + r;
+      }
+    }
+  }
+}
+
+template <int D, int QB, int NW, int NST, int OCC>
+int launch(float* x, int64_t ldx, const float* gamma, const float* beta, const half_t* w1, const float* b1, const half_t* w2,
+           const float* b2, int64_t rows, float eps, hipStream_t st) {
+  constexpr int DP = D <= 128 ? 128 : 256;
+  const size_t smem = (size_t)NST * (HC * DP * 2 + DP * 64) + 4 * D * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mlp_kernel<D, QB, NW, NST, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem));
+    attr_set = true;
+  }
+  const int64_t per = NW * 16 * QB;
+  const int64_t nb = (rows + per - 1) / per;
+  LMX_REQUIRE(nb < 0x7fffffffll, "lmx_k_ln_mlp: too many rows");
+  hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, gamma, beta, w1, b1, w2, b2, rows,
+                     eps);
+  return lmx_launch_check("ln_mlp_kernel");
+}
+
+}  // namespace lmx_mlp
+using namespace lmx_mlp;
+
+extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const float* beta, const void* w1, const float* b1,
+                            const void* w2, const float* b2, int64_t rows, int D, float eps, lmx_stream_t stream) {
+  LMX_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2, "lmx_k_ln_mlp: null pointer");
+  LMX_REQUIRE(D == 112 || D == 224, "lmx_k_ln_mlp: D=%d (built for the Hiera stage widths 112 and 224)", D);
+  LMX_REQUIRE(rows > 0 && ldx >= D && ldx % 4 == 0, "lmx_k_ln_mlp: rows=%lld ldx=%lld", (long long)rows, (long long)ldx);
+  LMX_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(beta) && aligned16(w1) && aligned16(b1) && aligned16(w2) && aligned16(b2),
+              "lmx_k_ln_mlp: pointers must be 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const half_t* W1 = reinterpret_cast<const half_t*>(w1);
+  const half_t* W2 = reinterpret_cast<const half_t*>(w2);
+  static int variant = -1;
+  if (variant < 0) {
+    const char* e = getenv("LMX_MLP_VARIANT");
+    variant = e ? e[0] - '0' : 0;
+  }
+  if (D == 112) {
+    if (variant == 1) return launch<112, 2, 4, 4, 2>(x, ldx, gamma, beta, W1, b1, W2, b2, rows, eps, st);
+    return launch<112, 2, 4, 3, 3>(x, ldx, gamma, beta, W1, b1, W2, b2, rows, eps, st);
+  }
+  if (variant == 1) return launch<224, 1, 8, 4, 1>(x, ldx, gamma, beta, W1, b1, W2, b2, rows, eps, st);
+  return launch<224, 2, 8, 4, 1>(x, ldx, gamma, beta, W1, b1, W2, b2, rows, eps, st);
+}

@@ -181,10 +181,10 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
   unsigned long long area = 0, sumx = 0, sumy = 0;
   int minx = 0x7fffffff, miny = 0x7fffffff, maxx = -1, maxy = -1;
   const int wq = (w + 3) / 4;
-  const int64_t total = (int64_t)h * wq;
+  const int total = h * wq;  // < 2^31 (checked by the launcher)
   uint8_t* mk = mask + (int64_t)b * h * w;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int xq = (int)(i % wq) * 4, y = (int)(i / wq);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int y = i / wq, xq = (i - y * wq) * 4;
     int Y0, Y1;
     float ly;
     bil_idx(sy, y, nh, Y0, Y1, ly);
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
       for (int e = 0; e < 4 && xq + e < w; ++e) mk[(int64_t)y * w + xq + e] = (packed >> (8 * e)) & 1;
     }
   }
-  // wave reduction then one atomic per wave
+  // wave reduction, then block reduction through LDS, then ONE set of atomics per block: same-address 64-bit atomics
+  // serialise at the memory side, so their count (blocks per frame x 7), not the pixel work, used to set this kernel's time
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     area += __shfl_xor(area, o, 64);
@@ -230,15 +231,39 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
     maxx = a3 > maxx ? a3 : maxx;
     maxy = a4 > maxy ? a4 : maxy;
   }
-  if ((threadIdx.x & 63) == 0 && area) {
-    unsigned long long* st = stats + (int64_t)b * 8;
-    atomicAdd(&st[0], area);
-    atomicAdd(&st[1], sumx);
-    atomicAdd(&st[2], sumy);
-    atomicMin(reinterpret_cast<long long*>(&st[3]), (long long)minx);
-    atomicMin(reinterpret_cast<long long*>(&st[4]), (long long)miny);
-    atomicMax(reinterpret_cast<long long*>(&st[5]), (long long)maxx);
-    atomicMax(reinterpret_cast<long long*>(&st[6]), (long long)maxy);
+  __shared__ unsigned long long red_s[4][3];
+  __shared__ int red_b[4][4];
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red_s[wv][0] = area;
+    red_s[wv][1] = sumx;
+    red_s[wv][2] = sumy;
+    red_b[wv][0] = minx;
+    red_b[wv][1] = miny;
+    red_b[wv][2] = maxx;
+    red_b[wv][3] = maxy;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      area += red_s[k][0];
+      sumx += red_s[k][1];
+      sumy += red_s[k][2];
+      minx = red_b[k][0] < minx ? red_b[k][0] : minx;
+      miny = red_b[k][1] < miny ? red_b[k][1] : miny;
+      maxx = red_b[k][2] > maxx ? red_b[k][2] : maxx;
+      maxy = red_b[k][3] > maxy ? red_b[k][3] : maxy;
+    }
+    if (area) {
+      unsigned long long* st = stats + (int64_t)b * 8;
+      atomicAdd(&st[0], area);
+      atomicAdd(&st[1], sumx);
+      atomicAdd(&st[2], sumy);
+      atomicMin(reinterpret_cast<long long*>(&st[3]), (long long)minx);
+      atomicMin(reinterpret_cast<long long*>(&st[4]), (long long)miny);
+      atomicMax(reinterpret_cast<long long*>(&st[5]), (long long)maxx);
+      atomicMax(reinterpret_cast<long long*>(&st[6]), (long long)maxy);
+    }
   }
 }
 
@@ -351,11 +376,12 @@ extern "C" int lmx_k_hyper_mask(const void* up, const float* hyper, float* logit
 extern "C" int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh, int nw, int h, int w, uint8_t* mask, int64_t* stats,
                                float* workspace, lmx_stream_t stream) {
   LMX_REQUIRE(logits && mask && stats && workspace, "lmx_k_mask_post: null pointer");
-  LMX_REQUIRE(n > 0 && L > 0 && T >= L && nh > 0 && nw > 0 && nh <= T && nw <= T && h > 0 && w > 0, "lmx_k_mask_post: geometry");
+  LMX_REQUIRE(n > 0 && L > 0 && T >= L && nh > 0 && nw > 0 && nh <= T && nw <= T && h > 0 && w > 0 &&
+                  (int64_t)h * ((w + 3) / 4) < 0x7fffffffll - 96 * 256 && n <= 65535, "lmx_k_mask_post: geometry");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, st, reinterpret_cast<long long*>(stats), n);
   int gx = (int)(((int64_t)h * ((w + 3) / 4) + 255) / 256);
-  if (gx > 1024) gx = 1024;
+  if (gx > 96) gx = 96;  // 96 blocks x n frames: >= 3000 blocks at the bench batch, and only 96 x 7 atomics per frame
   hipLaunchKernelGGL(mask_mid_kernel, dim3(grid_for((int64_t)n * nh * nw)), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw);
   hipLaunchKernelGGL(mask_post_kernel, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask,
                      reinterpret_cast<unsigned long long*>(stats));

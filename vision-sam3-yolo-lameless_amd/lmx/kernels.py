@@ -176,6 +176,22 @@ def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16, act=ACT_NO
     return out
 
 
+FUSED_MLP_WIDTHS = (112, 224)
+
+
+def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps):
+    """x (f32 [rows, D], updated in place) += fc2(gelu(fc1(LayerNorm(x)))) for D in FUSED_MLP_WIDTHS (csrc/mlp.hip)."""
+    _dev(x, gamma, beta, w1, b1, w2, b2)
+    rows, D, ldx = _rows(x, "ln_mlp x")
+    if x.dtype != torch.float32 or w1.dtype != torch.float16 or w2.dtype != torch.float16:
+        raise LmxError("ln_mlp: x must be f32 and the weights f16")
+    if tuple(w1.shape) != (4 * D, D) or tuple(w2.shape) != (D, 4 * D) or not (w1.is_contiguous() and w2.is_contiguous()):
+        raise LmxError("ln_mlp: weight shapes must be [4D, D] and [D, 4D], contiguous")
+    check(_lib.load().lmx_k_ln_mlp(_ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), rows, D,
+                                   float(eps), _stream()), "lmx_k_ln_mlp")
+    return x
+
+
 def _attn_desc(q, k, v, out, B, H, Tq, Tk, hd, scale, window, pad_k, pad_v):
     d = AttnDesc()
     d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()

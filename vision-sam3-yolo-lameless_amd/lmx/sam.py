@@ -107,9 +107,10 @@ class HieraEncoder:
     """Device-resident Hiera trunk + FPN.  ``encode(frames)`` -> dict(fpn=[3 NHWC f16 levels, high->low res],
     stages=[4 f32 stage outputs]).  Token grids are [n, H, W, C] row-major throughout (no partition copies)."""
 
-    def __init__(self, cfg, state_dict, device="cuda"):
+    def __init__(self, cfg, state_dict, device="cuda", fused_mlp=True):
         self.cfg = cfg
         self.device = torch.device(device)
+        self.fused_mlp = fused_mlp  # False: LN / GEMM / GEMM launches for every width (A/B comparisons and tests)
         dev = self.device
         sd = state_dict
 
@@ -220,9 +221,12 @@ class HieraEncoder:
             xo = torch.empty((n * H * W, D), dtype=torch.float32, device=dev) if res is not x else x
             K.gemm(a, B["wo"], bias=B["bo"], res=res, out=xo)
             x = xo
-            h2 = K.layernorm(x, B["g2"], B["b2"], cfg.eps)
-            u = K.gemm(h2, B["w1"], bias=B["bb1"], act=K.ACT_GELU)
-            K.gemm(u, B["w2"], bias=B["bb2"], res=x, out=x)
+            if D in K.FUSED_MLP_WIDTHS and self.fused_mlp:
+                K.ln_mlp(x, B["g2"], B["b2"], B["w1"], B["bb1"], B["w2"], B["bb2"], cfg.eps)  # one pass over x (csrc/mlp.hip)
+            else:
+                h2 = K.layernorm(x, B["g2"], B["b2"], cfg.eps)
+                u = K.gemm(h2, B["w1"], bias=B["bb1"], act=K.ACT_GELU)
+                K.gemm(u, B["w2"], bias=B["bb2"], res=x, out=x)
             if i in stage_ends:
                 stages.append(x.view(n, H, W, D))
                 if i != len(self.blocks) - 1 and self.blocks[i + 1]["dim"] == self.blocks[i + 1]["dim_out"]:
