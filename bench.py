@@ -66,6 +66,23 @@ def cpu_baseline(n_frames, clip_seed):
             "sample": f"{n_frames} synthetic 1080p frames, YOLOv8-l + Hiera-B+ encoder + SAM mask decoder + DINOv3 ViT-L/16, fp32 PyTorch CPU, batch 1"}
 
 
+def pmc_gemm_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes of this same command (tools/pmc.sh ->
+    tools/pmc_summary.py -> profiles/r01_pmc_summary.json; FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE),
+    launch-weighted over the GEMM kernels.  Counters cannot be read inside the timed run, so this is the profiled figure."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rows = json.load(f)
+    n = b = 0.0
+    for name, r in rows.items():
+        if "gemm2_kernel" in name or "gemm_kernel" in name:
+            n += r["launches"]
+            b += r["launches"] * (r["read_MB"] + r["write_MB"]) * 1e6
+    return b / n if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,9 +165,10 @@ def main():
                                    "HBM; synthetic weights",
                        "frames_per_gpu_per_step": args.frames, "parallelism": f"frames sharded over {world} GPU(s)",
                        "gflop_per_frame": sum(GFLOP_PER_FRAME.values())},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (lmx_k_gemm: all Linear / 1x1 / 3x3-implicit-GEMM launches)",
+            "roofline": {"bound": "mfma", "kernel": "gemm2_kernel / gemm_kernel (lmx_k_gemm: every Linear, 1x1 and 3x3-implicit-GEMM launch)",
                          "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
-                         "traffic": None, "launches_per_step": g_launches // max(args.steps, 1),
+                         "traffic": pmc_gemm_traffic(), "launches_per_step": g_launches // max(args.steps, 1),
+                         "flop_per_launch": g_flops / max(g_launches, 1),
                          "gemm_time_share": g_secs / dt if dt > 0 else None},
         }
         if not args.no_cpu_baseline and world == 1:

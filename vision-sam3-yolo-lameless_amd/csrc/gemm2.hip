@@ -34,7 +34,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // so that a k-tile lies inside one filter tap: the tap (ky,kx) is then wave-uniform per k-tile and a lane only adds a
 // constant to its pixel offset; out-of-image taps take the out-of-range offset and the descriptor returns zeros.
 template <int OUT_DT, int BM, int BN, int BK, int NSTAGE, int AMODE>
-__global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p) {
+__global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p, const int ntiles) {
   constexpr int NWAVE = (BM / 64) * (BN / 64);
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int A_INSTR = BM * BK * 2 / 1024 / NWAVE;  // LDS-DMA wave-instructions (1 KB each) per wave per k-tile
@@ -48,10 +48,18 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % (BM / 64), wn = wave / (BM / 64);  // (BM/64)(m) x 2(n) waves, 64 x 64 outputs each
 
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs; XCD x owns the contiguous tile range
+  // [base, base + cnt) (n fastest, so the n-tiles of one A row panel share that XCD's L2).  With gridDim.x < ntiles the
+  // workgroup is PERSISTENT and walks its XCD's range with the stride of the workgroups resident there: no block launch,
+  // no end-of-kernel store drain and no cold prologue between two tiles.
+  const int bid = blockIdx.x, xcd = bid & 7;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  const int stride = ((int)gridDim.x + 7 - xcd) >> 3;  // workgroups on this XCD
   const int NT = (p.N + BN - 1) / BN;
+  for (int li = bid >> 3; li < cnt; li += stride) {
+  const int swz = base + li;
   const int mt = swz / NT, nt = swz - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
 
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p) {
   // in registers on the way in.
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last k-tile
 #ifdef LMX_DBG_NOEPI
-  if (p.M > 0 && acc[0][0][0] != 12345.f) return;  // development probe: no epilogue
+  if (p.M > 0 && acc[0][0][0] != 12345.f) continue;  // development probe: no epilogue
 #endif
   const int act = p.act;
   char* my = smem + wave * 4608;  // 32 rows x 144 B (f16) or 16 rows x 272 B (f32) per pass
@@ -273,6 +281,8 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p) {
       }
     }
   }
+  __builtin_amdgcn_s_barrier();  // the staging slices are ring memory: nobody restages it before every wave has read its slice
+  }  // tile loop
 }
 
 template <int BM, int BN, int BK, int NSTAGE, int AMODE>
@@ -287,10 +297,18 @@ int launch2(const lmx_gemm_desc& d, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
+  const int ntiles = MT * NT;
+  int grid = ntiles;
+  static int persist = -1;  // LMX_GEMM2_PERSIST = workgroups per CU of the persistent grid (0: one workgroup per tile)
+  if (persist < 0) {
+    const char* e = getenv("LMX_GEMM2_PERSIST");
+    persist = e ? atoi(e) : 0;
+  }
+  if (persist > 0 && grid > 256 * persist) grid = 256 * persist;
   if (d.out_dtype == LMX_F16)
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE>), dim3(MT * NT), dim3(BM * BN / 64), smem, st, d);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles);
   else
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE>), dim3(MT * NT), dim3(BM * BN / 64), smem, st, d);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles);
   return lmx_launch_check("gemm2_kernel");
 }
 
