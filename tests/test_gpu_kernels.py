@@ -182,7 +182,9 @@ def _attn_ref(q, k, v, scale):
     return w @ v
 
 
-@pytest.mark.parametrize("B,H,T,hd", [(2, 16, 201, 64), (3, 2, 64, 56), (1, 4, 300, 32), (2, 3, 16, 64), (1, 2, 1000, 56)])
+# T >= 256 takes the LDS-DMA ring (attn.hip DMA path): ragged last tile, head-dim padding chunks, one / many key tiles
+@pytest.mark.parametrize("B,H,T,hd", [(2, 16, 201, 64), (3, 2, 64, 56), (1, 4, 300, 32), (2, 3, 16, 64), (1, 2, 1000, 56),
+                                      (2, 3, 257, 64), (3, 2, 256, 56), (1, 2, 4096, 56), (2, 1, 1153, 48)])
 def test_attention_flat(cuda, B, H, T, hd):
     from lmx import kernels as Kk
 

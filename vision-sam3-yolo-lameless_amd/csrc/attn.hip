@@ -22,6 +22,7 @@
 // double-buffered: one barrier per 64-key tile.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -67,10 +68,16 @@ __device__ __forceinline__ half4_t lds_tr_read(const half_t* p) {
 // QB: 16-query blocks per wave.  ONES: head dim <= 56, so V's (zero) column 63 is set to 1 and the PV MFMA itself
 // accumulates the softmax normaliser in O[:,63] — no row-sum instructions at all.
 // REL: SAM v1 decomposed relative-position bias read from the per-query tables of relpos_tables_kernel.
-template <int QB, bool ONES, bool REL>
+// DMA (flat geometry only): K/V tiles arrive by LDS-DMA (buffer_load ... lds) into a 3-slot ring, two tiles in flight, a
+// counted s_waitcnt vmcnt + one raw s_barrier per tile.  The register-staged path loads a tile at the top of an
+// iteration and stores it to LDS at the bottom of the SAME iteration: with 64 key tiles per query block (Hiera global
+// attention, T = 4096) every iteration then waits out an L2/HBM latency.
+template <int QB, bool ONES, bool REL, bool DMA>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, const Geo geo, const int nQT) {
-  __shared__ __attribute__((aligned(16))) half_t Ks[2][64 * 64];
-  __shared__ __attribute__((aligned(16))) half_t Vs[2][64 * 64];  // row-major [key][d], same swizzle as K
+  constexpr int NSL = DMA ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) half_t Ks[NSL][64 * 64];
+  __shared__ __attribute__((aligned(16))) half_t Vs[NSL][64 * 64];  // row-major [key][d], same swizzle as K
+  static_assert(!(DMA && REL), "the relative-position bias is read from global memory inside the loop: vmcnt would not count DMAs only");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -82,8 +89,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
     const int n = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n >> 3, r = n & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int qt = bid % nQT;
-  bid /= nQT;
+  const int nQTa = nQT < 0 ? -nQT : nQT;  // development switch: a negative count turns the lazy rescale off
+  const int qt = bid % nQTa;
+  bid /= nQTa;
   const int h = bid % p.H;
   const int b = bid / p.H;
 
@@ -191,16 +199,62 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
   // transposed-read addressing of the V fragment: lane (q4 = (lane&15)>>2, p4 = lane&3) of a 16-lane group points at
   // row key0+q4, columns 16*db + 4*p4 .. +3
   const int q4 = fr >> 2, p4 = fr & 3;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  // ---- LDS-DMA plan (DMA): wave w stages KB pieces 2w, 2w+1 of the K tile and of the V tile (8 rows x 128 B each);
+  // the (chunk ^ row&7) swizzle goes on the per-lane SOURCE address, head-dim padding chunks and keys >= Tk fall outside
+  // the descriptor (the row offset is in voffset, which the range check covers) and read as zeros.
+  constexpr int LA = 2, PT = 4;
+  __amdgpu_buffer_rsrc_t k_rs, v_rs;
+  unsigned kvo[2], vvo[2];
+  if constexpr (DMA) {
+    const int64_t kb = ((int64_t)(p.Tk - 1) * p.ldk + hd) * 2, vb = ((int64_t)(p.Tk - 1) * p.ldv + hd) * 2;  // < 2^31: launcher
+    k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(K + (int64_t)b * p.Tk * p.ldk + (int64_t)h * hd), 0, (int)kb, 0x00020000);
+    v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(V + (int64_t)b * p.Tk * p.ldv + (int64_t)h * hd), 0, (int)vb, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave * 2 + j) * 8 + (lane >> 3);
+      const int lc = (lane & 7) ^ (row & 7);
+      const bool ok = lc * 8 < hd;
+      kvo[j] = ok ? (unsigned)(row * (int)p.ldk * 2 + lc * 16) : 0x80000000u;
+      vvo[j] = ok ? (unsigned)(row * (int)p.ldv * 2 + lc * 16) : 0x80000000u;
+    }
+  }
+  auto issue = [&](int it, int slot) {
+    const unsigned ko = (unsigned)(it * 64 * (int)p.ldk * 2), vo = (unsigned)(it * 64 * (int)p.ldv * 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      lds_dma16(k_rs, reinterpret_cast<char*>(&Ks[slot][0]) + (wave * 2 + j) * 1024, kvo[j] == 0x80000000u ? kvo[j] : kvo[j] + ko, 0);
+      lds_dma16(v_rs, reinterpret_cast<char*>(&Vs[slot][0]) + (wave * 2 + j) * 1024, vvo[j] == 0x80000000u ? vvo[j] : vvo[j] + vo, 0);
+    }
+  };
+  if constexpr (DMA) {
+#pragma unroll
+    for (int t = 0; t < LA; ++t)
+      if (t < ntile) issue(t, t);
+  } else {
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+  }
   // The body is instantiated twice: full tiles carry NO masking code at all (hipcc otherwise if-converts the
   // wave-uniform `partial` test into a compare+select per score element: ~60 VALU per tile), the last tile masks.
   auto tile_body = [&](const int it, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
     const int t0 = it * 64;
-    const int buf = it & 1;
-    if (it + 1 < ntile) load_tile(t0 + 64);
+    int buf;
+    if constexpr (DMA) {
+      // tile `it` has landed once only this wave's DMAs of the next tile are outstanding (Q's loads are older; nothing else
+      // is loaded from global memory in the loop)
+      if (it + 1 < ntile)
+        wait_vmcnt<PT>();
+      else
+        wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (it + LA < ntile) issue(it + LA, (it + LA) % 3);
+      buf = it % 3;
+    } else {
+      buf = it & 1;
+      if (it + 1 < ntile) load_tile(t0 + 64);
+    }
 
     // ---- S^T = K . Q^T  (raw, unscaled)
     f32x4 sacc[QB][4];
@@ -250,7 +304,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[qb], mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * sl2);
+      // the running maximum settles after the first few key tiles: rescale the accumulators only when some query of
+      // the wave raised it (wave-uniform branch) — saves an exp2 and 16 multiplies per query block and tile
+      // (flat geometry only: measured slower on the windowed shapes, whose four key tiles mostly do raise the maximum)
+      const bool grew = nQT < 0 || __builtin_amdgcn_ballot_w64(m_new > m_run[qb]) != 0;
+      const float alpha = grew ? __builtin_amdgcn_exp2f((m_run[qb] - m_new) * sl2) : 1.0f;
       m_run[qb] = m_new;
       const float mb = m_new * sl2;
       float rs = 0.f;
@@ -267,8 +325,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
           pf[qb][kb >> 1][(kb & 1) * 4 + r + 1] = e[1];
         }
       if (!ONES) l_run[qb] = l_run[qb] * alpha + rs;
+      if (grew) {
 #pragma unroll
-      for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
+        for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
+      }
     }
 
     // ---- O^T += V^T . P^T   (V^T fragments by hardware-transposed LDS reads of the row-major V tile)
@@ -280,15 +340,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
         const int r0 = ks * 32 + fg * 4 + q4, r1 = r0 + 16;
         const half4_t lo = lds_tr_read(&Vs[buf][r0 * 64 + ((chunk ^ (r0 & 7)) << 3) + (p4 & 1) * 4]);
         const half4_t hi = lds_tr_read(&Vs[buf][r1 * 64 + ((chunk ^ (r1 & 7)) << 3) + (p4 & 1) * 4]);
-        const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (DMA && ONES && db == 3) {  // row d = 63 of V^T (lanes fr == 15) is the ones row: the staged tile holds zeros there
+          const half_t one = (half_t)1.0f;
+          const half8_t ones8 = {one, one, one, one, one, one, one, one};
+          vf = fr == 15 ? ones8 : vf;
+        }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
           oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][ks], oacc[qb][db], 0, 0, 0);
       }
     }
 
-    if (it + 1 < ntile) store_tile(buf ^ 1);
-    __syncthreads();
+    if constexpr (!DMA) {
+      if (it + 1 < ntile) store_tile(buf ^ 1);
+      __syncthreads();
+    }
   };
   for (int it = 0; it + 1 < ntile; ++it) tile_body(it, std::false_type{});
   if (p.Tk & 63)
@@ -409,25 +476,38 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
 
   const bool big = d.Tq > 64;
   const int qtile = big ? 128 : 64;
-  const int nQT = (d.Tq + qtile - 1) / qtile;
+  int nQT = (d.Tq + qtile - 1) / qtile;
   const int64_t nblk = (int64_t)d.B * d.H * nQT;
   LMX_REQUIRE(nblk < (1ll << 31), "lmx_k_attention: grid too large");
   const bool ones = d.hd <= 56;
+  // LDS-DMA staging: flat geometry without bias, at least a few key tiles, per-(batch) K/V extent within a 31-bit buffer
+  static int no_dma = -1, no_lazy = 0;
+  if (no_dma < 0) {
+    no_dma = getenv("LMX_ATTN_NO_DMA") ? 1 : 0;
+    no_lazy = getenv("LMX_ATTN_NO_LAZY") ? 1 : 0;
+  }
+  const bool dma = !no_dma && d.mode == 0 && !d.rel && big && d.Tk >= 256 && (int64_t)d.Tk * d.ldk * 2 < 0x7fff0000ll &&
+                   (int64_t)d.Tk * d.ldv * 2 < 0x7fff0000ll;
+  if (no_lazy) nQT = -nQT;
   if (d.rel) {
     LMX_REQUIRE(d.rel_S > 0 && d.rel_S * d.rel_S == d.Tk && d.Tq == d.Tk, "lmx_k_attention: rel_S=%d does not match Tq=%d Tk=%d",
                 d.rel_S, d.Tq, d.Tk);
     if (big)
-      hipLaunchKernelGGL((attn_kernel<2, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+      hipLaunchKernelGGL((attn_kernel<2, false, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
     else
-      hipLaunchKernelGGL((attn_kernel<1, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
-  } else if (big && ones)
-    hipLaunchKernelGGL((attn_kernel<2, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+      hipLaunchKernelGGL((attn_kernel<1, false, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  } else if (dma && ones)
+    hipLaunchKernelGGL((attn_kernel<2, true, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  else if (dma)
+    hipLaunchKernelGGL((attn_kernel<2, false, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  else if (big && ones)
+    hipLaunchKernelGGL((attn_kernel<2, true, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else if (big)
-    hipLaunchKernelGGL((attn_kernel<2, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    hipLaunchKernelGGL((attn_kernel<2, false, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else if (ones)
-    hipLaunchKernelGGL((attn_kernel<1, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    hipLaunchKernelGGL((attn_kernel<1, true, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else
-    hipLaunchKernelGGL((attn_kernel<1, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    hipLaunchKernelGGL((attn_kernel<1, false, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   return lmx_launch_check("attn_kernel");
 }
 
