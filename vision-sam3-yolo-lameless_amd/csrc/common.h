@@ -86,17 +86,40 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst_l
 
 // counted wait with a literal immediate per instantiation (an "n"-constrained template-dependent asm operand makes
 // hipcc drop the HOST stub of the enclosing kernel template without a diagnostic)
+#define LMX_WAIT_CASE(n) \
+  if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal for this count");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8 || N == 9 || N == 12 || N == 16 || N == 18 || N == 24 ||
+                    N == 32,
+                "add the literal for this count");
+  LMX_WAIT_CASE(0);
+  LMX_WAIT_CASE(2);
+  LMX_WAIT_CASE(3);
+  LMX_WAIT_CASE(4);
+  LMX_WAIT_CASE(6);
+  LMX_WAIT_CASE(8);
+  LMX_WAIT_CASE(9);
+  LMX_WAIT_CASE(12);
+  LMX_WAIT_CASE(16);
+  LMX_WAIT_CASE(18);
+  LMX_WAIT_CASE(24);
+  LMX_WAIT_CASE(32);
+}
+#undef LMX_WAIT_CASE
+// wait until at most y * PT of this wave's vector-memory operations are outstanding (y = 0..4 whole k-tiles of PT DMAs)
+template <int PT>
+__device__ __forceinline__ void wait_tiles(int y) {
+  if (y >= 4)
+    wait_vmcnt<4 * PT>();
+  else if (y == 3)
+    wait_vmcnt<3 * PT>();
+  else if (y == 2)
+    wait_vmcnt<2 * PT>();
+  else if (y == 1)
+    wait_vmcnt<PT>();
+  else
+    wait_vmcnt<0>();
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -33,8 +33,19 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // AMODE 1: A is generated from an NHWC image batch (3x3, pad 1, stride 1|2; gemm.hip's a_mode 1) — requires Cin % BK == 0
 // so that a k-tile lies inside one filter tap: the tap (ky,kx) is then wave-uniform per k-tile and a lane only adds a
 // constant to its pixel offset; out-of-image taps take the out-of-range offset and the descriptor returns zeros.
-template <int OUT_DT, int BM, int BN, int BK, int NSTAGE, int AMODE>
-__global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p, const int ntiles) {
+// STAG 1: the two halves of the waves (w and w + NWAVE/2 share a SIMD) run ONE barrier interval apart, and a k-tile is
+// two intervals: X = fragment reads + counted vmcnt + next LDS-DMA, Y = the MFMAs.  While one wave of a SIMD is in Y the
+// other is in X: the matrix pipe sees MFMAs in every interval instead of every second one (guide: 8-phase template).
+// waves per SIMD the register allocation must allow: two workgroups per CU when the ring leaves room for them.  Stated as
+// a thread bound (waves x 256 threads = that many waves on each of the 4 SIMDs) rather than as a minimum-occupancy hint: the
+// hint makes hipcc schedule up to the cap and spill a few registers in the 128-register kernels.
+constexpr int waves_per_simd(int BM, int BN, int BK, int NSTAGE) {
+  const int smem = NSTAGE * (BM + BN) * BK * 2, nwave = (BM / 64) * (BN / 64);
+  const int wps = (smem <= 80 * 1024 ? 2 : 1) * nwave / 4;
+  return wps < 1 ? 1 : wps;
+}
+template <int OUT_DT, int BM, int BN, int BK, int NSTAGE, int AMODE, int STAG>
+__global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm2_kernel(const lmx_gemm_desc p, const int ntiles) {
   constexpr int NWAVE = (BM / 64) * (BN / 64);
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int A_INSTR = BM * BK * 2 / 1024 / NWAVE;  // LDS-DMA wave-instructions (1 KB each) per wave per k-tile
@@ -150,21 +161,12 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p, cons
 
   const int frow = lane & 15, fq = lane >> 4;
   const int fsw = (BK == 64) ? (frow & 7) : ((-(frow >> 2)) & 3);
+  constexpr int PT = A_INSTR + W_INSTR;
+  if constexpr (STAG == 0) {
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once only the LDS-DMAs of the (at most LA-1) younger tiles are outstanding
-    constexpr int PT = A_INSTR + W_INSTR;
     const int left = nk - 1 - kt;
-    const int younger = left < LA - 1 ? left : LA - 1;
-    if (LA >= 5 && younger >= 4)
-      wait_vmcnt<(LA >= 5 ? 4 : 0) * PT>();
-    else if (LA >= 4 && younger == 3)
-      wait_vmcnt<(LA >= 4 ? 3 : 0) * PT>();
-    else if (LA >= 3 && younger == 2)
-      wait_vmcnt<(LA >= 3 ? 2 : 0) * PT>();
-    else if (younger == 1)
-      wait_vmcnt<PT>();
-    else
-      wait_vmcnt<0>();
+    wait_tiles<PT>(left < LA - 1 ? left : LA - 1);
     __builtin_amdgcn_s_barrier();
     if (kt + LA < nk) issue(kt + LA, (kt + LA) % NSTAGE);
     const char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
@@ -189,6 +191,51 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p, cons
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
+  }
+  } else {
+  // ---- staggered two-interval schedule.  Interval numbering: group 0 runs X(kt) in interval 2kt and Y(kt) in 2kt+1,
+  // group 1 one interval later.  RAW: tile kt+1 is retired by every wave's counted vmcnt in its X(kt) (intervals 2kt,
+  // 2kt+1) and first read in X(kt+1) (intervals >= 2kt+2).  WAR: X(kt) restages the slot of tile kt-1, whose last reads
+  // (group 1's X(kt-1), interval 2kt-1, drained by lgkmcnt(0) before its barrier) precede interval 2kt.
+  const int grp = wave >= NWAVE / 2 ? 1 : 0;
+  {
+    const int y = nk - 1 < LA - 1 ? nk - 1 : LA - 1;  // tiles 1.. may stay in flight; tile 0 must have landed
+    wait_tiles<PT>(y);
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp) __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
+    const half_t* as = reinterpret_cast<const half_t*>(st) + (wm * 64 + frow) * BK;
+    const half_t* ws = reinterpret_cast<const half_t*>(st + BM * BK * 2) + (wn * 64 + frow) * BK;
+    half8_t af[BK / 32][4], wf[BK / 32][4];
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int coff = (((ks << 2) + fq) ^ fsw) << 3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[ks][j] = *reinterpret_cast<const half8_t*>(ws + j * 16 * BK + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const half8_t*>(as + i * 16 * BK + coff);
+    }
+    if (kt + 1 < nk) {
+      const int rest = nk - 2 - kt;  // tiles younger than kt+1 that exist
+      wait_tiles<PT>(rest < LA - 2 ? (rest < 0 ? 0 : rest) : (LA - 2 < 0 ? 0 : LA - 2));
+    }
+    if (kt + LA < nk) issue(kt + LA, (kt + LA) % NSTAGE);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!grp) __builtin_amdgcn_s_barrier();  // re-align the two groups
   }
 
   // ---- epilogue through LDS.  In the accumulator a lane owns 4 channels of 16 different rows, so direct stores are
@@ -285,15 +332,15 @@ __global__ __launch_bounds__(1024) void gemm2_kernel(const lmx_gemm_desc p, cons
   }  // tile loop
 }
 
-template <int BM, int BN, int BK, int NSTAGE, int AMODE>
+template <int BM, int BN, int BK, int NSTAGE, int AMODE, int STAG = 0>
 int launch2(const lmx_gemm_desc& d, hipStream_t st) {
   const int MT = (d.M + BM - 1) / BM, NT = (d.N + BN - 1) / BN;
   const size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;  // >= NWAVE * 4608 B of epilogue staging for every variant
   static bool attr_set = false;
   if (!attr_set) {
-    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE>),
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE, STAG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE>),
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE, STAG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
@@ -306,9 +353,9 @@ int launch2(const lmx_gemm_desc& d, hipStream_t st) {
   }
   if (persist > 0 && grid > 256 * persist) grid = 256 * persist;
   if (d.out_dtype == LMX_F16)
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE, STAG>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles);
   else
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE, STAG>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles);
   return lmx_launch_check("gemm2_kernel");
 }
 
@@ -335,6 +382,10 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     case 'G': return launch2<256, 256, 32, 5, 0>(d, st);  // ... 160 KB ring: four k-tiles in flight
     case 'H': return launch2<128, 128, 32, 2, 0>(d, st);  // 4 waves, 32 KB: up to 4 blocks/CU for short-K (HBM-bound) shapes
     case 'I': return launch2<128, 128, 32, 3, 0>(d, st);  // 4 waves, 48 KB: 3 blocks/CU
+    case 'S': return launch2<256, 128, 32, 6, 0, 1>(d, st);  // staggered wave groups, 6 x 24 KB ring, 1 block/CU
+    case 'T': return launch2<256, 128, 64, 3, 0, 1>(d, st);  // staggered, 3 x 48 KB ring
+    case 'U': return launch2<256, 128, 32, 3, 0, 1>(d, st);  // staggered, 3 x 24 KB ring, 2 blocks/CU
+    case 'V': return launch2<256, 128, 32, 4, 0, 1>(d, st);  // staggered, 4 x 24 KB ring
     default:
       // measured on the model shapes (profiles/r01_gemm_variants.txt): with K <= ~2k the per-tile prologue/epilogue
       // dominates and two co-resident blocks (C) hide it; long-K problems prefer the deeper 64-wide ring (A)
