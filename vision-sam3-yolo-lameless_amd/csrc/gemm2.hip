@@ -386,9 +386,12 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     case 'T': return launch2<256, 128, 64, 3, 0, 1>(d, st);  // staggered, 3 x 48 KB ring
     case 'U': return launch2<256, 128, 32, 3, 0, 1>(d, st);  // staggered, 3 x 24 KB ring, 2 blocks/CU
     case 'V': return launch2<256, 128, 32, 4, 0, 1>(d, st);  // staggered, 4 x 24 KB ring
-    default:
-      // measured on the model shapes (profiles/r01_gemm_variants.txt): with K <= ~2k the per-tile prologue/epilogue
-      // dominates and two co-resident blocks (C) hide it; long-K problems prefer the deeper 64-wide ring (A)
-      return d.K >= 3072 ? launch2<256, 128, 64, 3, 0>(d, st) : launch2<256, 128, 32, 3, 0>(d, st);
+    default: {
+      // measured on the model shapes (profiles/r01_gemm_variants.txt, r01_gemm_staggered_variants.txt): with K < ~1.8k the
+      // per-tile prologue/epilogue dominates and two co-resident workgroups (C) hide it; long-K problems, and problems with
+      // no more tiles than CUs, prefer the staggered schedule on the 3 x 48 KB ring (T), one workgroup per CU
+      const int64_t tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128);
+      return (d.K >= 1792 || tiles <= 256) ? launch2<256, 128, 64, 3, 0, 1>(d, st) : launch2<256, 128, 32, 3, 0>(d, st);
+    }
   }
 }
