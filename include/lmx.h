@@ -240,6 +240,11 @@ int lmx_k_hyper_mask(const void* up, const float* hyper, float* logits, int n, i
  * workspace: n*nh*nw floats (the cropped TxT intermediate, so each output pixel costs 4 taps instead of 16). */
 int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh, int nw, int h, int w, uint8_t* mask,
                     int64_t* stats, float* workspace, lmx_stream_t stream);
+/* Bit-pack a 0/non-0 byte image: dst[r][c] holds pixels 8c..8c+7 of row r, first pixel in the most significant bit
+ * (numpy.packbits order); rows are padded to ceil(w/8) bytes.  Used for the mask persisted / gathered per frame
+ * (services/sam3-pipeline/app/main.py:83-89 returns a bool[H,W] mask; SURVEY.md §8b `mask_bits [n, h, ceil(w/8)]`):
+ * 8x less D2H and xGMI traffic than the byte mask. */
+int lmx_k_pack_bits(const uint8_t* src, int64_t rows, int w, uint8_t* dst, lmx_stream_t stream);
 
 /* ---- HOST function (mask pointer is HOST memory) ----------------------------------------------------------------------
  * extract_segmentation_features (sam3 main.py:102-145) on a 0/1 byte mask [h][w]: out[7] = mask_area, area_ratio,

@@ -352,3 +352,15 @@ def test_nms_known_answers(cuda):
     p = _pred([[0, 0, 10, 10]], [0.1], [0])
     _, _, _, src, cnt = _run_nms(cuda, p[None], 0.25)
     assert cnt[0] == 0
+
+
+# ------------------------------------------------------------------------------------------- mask bit-packing
+@pytest.mark.parametrize("shape", [(2, 1080, 1920), (1, 7, 13), (3, 5, 8), (1, 1, 1), (2, 33, 250)])
+def test_pack_bits_bit_exact(cuda, shape):
+    from lmx import kernels as Kk
+
+    m = (np.random.default_rng(90).random(shape) < 0.3).astype(np.uint8)
+    m[..., 0] *= 255  # any non-zero byte is a set pixel
+    got = Kk.pack_bits(torch.from_numpy(m).to(cuda)).cpu().numpy()
+    ref = np.packbits(m != 0, axis=-1)
+    assert got.shape == ref.shape and np.array_equal(got, ref)

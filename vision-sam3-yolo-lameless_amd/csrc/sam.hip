@@ -267,6 +267,28 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
   }
 }
 
+// thread = one output byte = 8 mask pixels, first pixel in the most significant bit (numpy.packbits order).  For 0/1
+// bytes loaded little-endian as one 64-bit word, (x * 0x8040201008040201) >> 56 gathers the eight low bits in that order.
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t* __restrict__ src, int64_t rows, int w, int wb,
+                                                        uint8_t* __restrict__ dst) {
+  const int64_t total = rows * wb;
+  const bool fast = (w & 7) == 0 && ((reinterpret_cast<uintptr_t>(src) & 7) == 0);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / wb;
+    const int c = (int)(i - r * wb);
+    const uint8_t* sp = src + r * w + (int64_t)c * 8;
+    unsigned long long x = 0;
+    if (fast) {
+      x = *reinterpret_cast<const unsigned long long*>(sp);
+    } else {
+      for (int e = 0; e < 8; ++e)
+        if (c * 8 + e < w) x |= (unsigned long long)sp[e] << (8 * e);
+    }
+    x = (x | (x >> 1) | (x >> 2) | (x >> 3) | (x >> 4) | (x >> 5) | (x >> 6) | (x >> 7)) & 0x0101010101010101ull;  // any non-zero byte -> 1
+    dst[i] = (uint8_t)((x * 0x8040201008040201ull) >> 56);
+  }
+}
+
 __global__ __launch_bounds__(256) void prompt_box_kernel(const float* __restrict__ boxes, int64_t ldb, float* __restrict__ sparse,
                                                         int n, double sx, double sy, float S, const float* __restrict__ gauss,
                                                         const float* __restrict__ corner, int F) {
@@ -386,4 +408,12 @@ extern "C" int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh,
   hipLaunchKernelGGL(mask_post_kernel, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask,
                      reinterpret_cast<unsigned long long*>(stats));
   return lmx_launch_check("mask_post_kernel");
+}
+
+extern "C" int lmx_k_pack_bits(const uint8_t* src, int64_t rows, int w, uint8_t* dst, lmx_stream_t stream) {
+  LMX_REQUIRE(src && dst, "lmx_k_pack_bits: null pointer");
+  LMX_REQUIRE(rows > 0 && w > 0, "lmx_k_pack_bits: rows=%lld w=%d", (long long)rows, w);
+  const int wb = (w + 7) / 8;
+  hipLaunchKernelGGL(pack_bits_kernel, dim3(grid_for(rows * wb)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, rows, w, wb, dst);
+  return lmx_launch_check("pack_bits_kernel");
 }

@@ -176,6 +176,18 @@ def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16, act=ACT_NO
     return out
 
 
+def pack_bits(mask):
+    """u8 [..., h, w] (0 / non-0) -> u8 [..., h, ceil(w/8)], numpy.packbits bit order."""
+    _dev(mask)
+    if mask.dtype not in (torch.uint8, torch.bool) or not mask.is_contiguous():
+        raise LmxError("pack_bits: contiguous uint8 / bool tensor expected")
+    w = mask.shape[-1]
+    rows = mask.numel() // w
+    out = torch.empty(tuple(mask.shape[:-1]) + ((w + 7) // 8,), dtype=torch.uint8, device=mask.device)
+    check(_lib.load().lmx_k_pack_bits(_ptr(mask), rows, w, _ptr(out), _stream()), "lmx_k_pack_bits")
+    return out
+
+
 FUSED_MLP_WIDTHS = (112, 224)
 
 

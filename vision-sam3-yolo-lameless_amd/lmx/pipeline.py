@@ -6,6 +6,7 @@ import os
 import torch
 
 from . import dino, sam, sam_decoder, yolo
+from . import kernels as K
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
 
@@ -26,8 +27,10 @@ class FusedExtractor:
         dcfg = dino.dinov3_vitl16()
         self.dino = dino.DinoEmbedder(dcfg, weights.synth_state_dict(dino.param_spec(dcfg), weight_seeds[2]), self.device)
 
-    def step(self, frames, conf=0.5, sam_chunk=32):
-        """frames u8 [n,1080,1920,3] BGR on device -> dict of device tensors for every frame (dense schedule)."""
+    def step(self, frames, conf=0.5, sam_chunk=32, keep_byte_masks=False):
+        """frames u8 [n,1080,1920,3] BGR on device -> dict of device tensors for every frame (dense schedule).  Masks are
+        returned bit-packed ([n, h, ceil(w/8)], numpy.packbits order): that is what is gathered across GPUs and copied to
+        the host; `keep_byte_masks` adds the u8 [n,h,w] masks the kernels produced."""
         n, h, w, _ = frames.shape
         boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf)
         emb = self.dino.embed_frames(frames)
@@ -42,5 +45,10 @@ class FusedExtractor:
             masks.append(d["mask"])
             stats.append(d["stats"])
             ious.append(d["iou"])
-        return dict(boxes=boxes, scores=scores, cls=cls, counts=counts, embedding=emb, mask=torch.cat(masks, 0),
-                    mask_stats=torch.cat(stats, 0), mask_iou=torch.cat(ious, 0))
+        cat = (lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, 0))
+        mask = cat(masks)
+        out = dict(boxes=boxes, scores=scores, cls=cls, counts=counts, embedding=emb, mask_bits=K.pack_bits(mask),
+                   mask_stats=cat(stats), mask_iou=cat(ious))
+        if keep_byte_masks:
+            out["mask"] = mask
+        return out
