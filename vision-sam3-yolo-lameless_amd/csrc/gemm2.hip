@@ -45,7 +45,7 @@ constexpr int waves_per_simd(int BM, int BN, int BK, int NSTAGE) {
   return wps < 1 ? 1 : wps;
 }
 template <int OUT_DT, int BM, int BN, int BK, int NSTAGE, int AMODE, int STAG>
-__global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm2_kernel(const lmx_gemm_desc p, const int ntiles) {
+__global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm2_kernel(const lmx_gemm_desc p, const int ntiles, const int nt_ok) {
   constexpr int NWAVE = (BM / 64) * (BN / 64);
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   constexpr int A_INSTR = BM * BK * 2 / 1024 / NWAVE;  // LDS-DMA wave-instructions (1 KB each) per wave per k-tile
@@ -248,6 +248,10 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   if (p.M > 0 && acc[0][0][0] != 12345.f) continue;  // development probe: no epilogue
 #endif
   const int act = p.act;
+  // a large f16 output whose rows are whole 128-byte lines streams past L2 (`nt`): written back normally it evicts the A
+  // and W panels the co-resident tiles are re-reading (measured: fc1 of Hiera stage 3 561 -> 628 TFLOP/s, stage 2 387 -> 549;
+  // ragged rows and the in-place f32 residual update lose with nt and keep the default policy)
+  const bool nt_out = nt_ok && OUT_DT == LMX_F16 && ((p.ldc * 2) & 127) == 0 && (int64_t)p.M * p.N >= (16ll << 20);
   char* my = smem + wave * 4608;  // 32 rows x 144 B (f16) or 16 rows x 272 B (f32) per pass
   f32x4 bia[4], scl[4];
 #pragma unroll
@@ -290,7 +294,11 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
           }
-          *reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n) = o;
+          half8_t* dst = reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n);
+          if (nt_out)  // (asm: hipcc merges a __builtin_nontemporal_store with the plain store of the other branch and drops nt)
+            asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(o) : "memory");
+          else
+            *dst = o;
         }
       }
     }
@@ -346,16 +354,17 @@ int launch2(const lmx_gemm_desc& d, hipStream_t st) {
   }
   const int ntiles = MT * NT;
   int grid = ntiles;
-  static int persist = -1;  // LMX_GEMM2_PERSIST = workgroups per CU of the persistent grid (0: one workgroup per tile)
+  static int persist = -1, nt_ok = 1;  // LMX_GEMM2_PERSIST = workgroups per CU of the persistent grid (0: one per tile)
   if (persist < 0) {
     const char* e = getenv("LMX_GEMM2_PERSIST");
     persist = e ? atoi(e) : 0;
+    nt_ok = getenv("LMX_GEMM2_NO_NT") ? 0 : 1;
   }
   if (persist > 0 && grid > 256 * persist) grid = 256 * persist;
   if (d.out_dtype == LMX_F16)
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE, STAG>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE, STAG>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles, nt_ok);
   else
-    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE, STAG>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles);
+    hipLaunchKernelGGL((gemm2_kernel<LMX_F32, BM, BN, BK, NSTAGE, AMODE, STAG>), dim3(grid), dim3(BM * BN / 64), smem, st, d, ntiles, nt_ok);
   return lmx_launch_check("gemm2_kernel");
 }
 
