@@ -17,6 +17,7 @@ class FusedExtractor:
         from . import weights
 
         self.device = torch.device(device)
+        self.serial = bool(os.environ.get("LMX_SERIAL"))  # True: every launch on the caller's stream
         ycfg = yolo.YoloConfig(yolo_scale)
         bn = yolo_bn or os.path.join(GOLDEN, f"yolov8{yolo_scale}_bn_w{weight_seeds[0]}.npz")
         self.yolo = yolo.YoloDetector(ycfg, yolo.synthetic_state_dict(ycfg, weight_seeds[0], bn if os.path.exists(bn) else None),
@@ -27,24 +28,51 @@ class FusedExtractor:
         dcfg = dino.dinov3_vitl16()
         self.dino = dino.DinoEmbedder(dcfg, weights.synth_state_dict(dino.param_spec(dcfg), weight_seeds[2]), self.device)
 
-    def step(self, frames, conf=0.5, sam_chunk=32, keep_byte_masks=False):
+    def _streams(self, k):
+        pool = getattr(self, "_pool", None)
+        if pool is None:
+            pool = self._pool = []
+        while len(pool) < k:
+            pool.append(torch.cuda.Stream(self.device))
+        return pool[:k]
+
+    def step(self, frames, conf=0.5, sam_chunk=16, keep_byte_masks=False):
         """frames u8 [n,1080,1920,3] BGR on device -> dict of device tensors for every frame (dense schedule).  Masks are
         returned bit-packed ([n, h, ceil(w/8)], numpy.packbits order): that is what is gathered across GPUs and copied to
         the host; `keep_byte_masks` adds the u8 [n,h,w] masks the kernels produced."""
         n, h, w, _ = frames.shape
-        boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf)
-        emb = self.dino.embed_frames(frames)
         rhw = sam.resize_longest_side(h, w, self.sam.cfg.image)
+        # The three networks only meet at the mask decoder (SAM's prompt = YOLO's top box), and frames are independent.
+        # YOLO + DINO run on one side stream and every SAM chunk of `sam_chunk` frames on its own: MFMA-bound GEMMs of one
+        # stream fill the CUs while another stream is in HBM-bound kernels (LayerNorm, narrow-stage attention, residual
+        # epilogues), and the tail of one launch overlaps the head of another.  `self.serial` (LMX_SERIAL=1) keeps one stream.
+        main = torch.cuda.current_stream(self.device)
+        chunks = list(range(0, n, sam_chunk))
+        if self.serial:
+            det_stream, sam_streams = main, [main] * len(chunks)
+        else:
+            pool = self._streams(1 + len(chunks))
+            det_stream, sam_streams = pool[0], pool[1:]
+            for st in pool:
+                st.wait_stream(main)  # frames were produced on the caller's stream
+        with torch.cuda.stream(det_stream):
+            boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf)
+            emb = self.dino.embed_frames(frames)
         masks, stats, ious = [], [], []
-        for i in range(0, n, sam_chunk):  # Hiera activations are ~100 MB/frame: bound the live set
-            enc = self.sam.encode(frames[i:i + sam_chunk])
-            e2 = enc["fpn"][2]
-            # the service prompts SAM with the first (highest-confidence) detection of the frame (sam3 main.py:199-206);
-            # frames without a detection are decoded against an all-zero box and flagged by counts == 0
-            d = self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes[i:i + sam_chunk, 0, :], (h, w), rhw)
+        for i, st in zip(chunks, sam_streams):  # Hiera activations are ~100 MB/frame: a chunk bounds the live set
+            with torch.cuda.stream(st):
+                enc = self.sam.encode(frames[i:i + sam_chunk])
+                e2 = enc["fpn"][2]
+                st.wait_stream(det_stream)  # the decoder needs the boxes
+                # the service prompts SAM with the first (highest-confidence) detection of the frame (sam3 main.py:199-206);
+                # frames without a detection are decoded against an all-zero box and flagged by counts == 0
+                d = self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes[i:i + sam_chunk, 0, :], (h, w), rhw)
             masks.append(d["mask"])
             stats.append(d["stats"])
             ious.append(d["iou"])
+        for st in set(sam_streams + [det_stream]):
+            if st is not main:
+                main.wait_stream(st)
         cat = (lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, 0))
         mask = cat(masks)
         out = dict(boxes=boxes, scores=scores, cls=cls, counts=counts, embedding=emb, mask_bits=K.pack_bits(mask),
