@@ -43,20 +43,21 @@ class FusedExtractor:
         n, h, w, _ = frames.shape
         rhw = sam.resize_longest_side(h, w, self.sam.cfg.image)
         # The three networks only meet at the mask decoder (SAM's prompt = YOLO's top box), and frames are independent.
-        # YOLO + DINO run on one side stream and every SAM chunk of `sam_chunk` frames on its own: MFMA-bound GEMMs of one
+        # YOLO, DINO and every SAM chunk of `sam_chunk` frames each run on a HIP stream of their own: MFMA-bound GEMMs of one
         # stream fill the CUs while another stream is in HBM-bound kernels (LayerNorm, narrow-stage attention, residual
         # epilogues), and the tail of one launch overlaps the head of another.  `self.serial` (LMX_SERIAL=1) keeps one stream.
         main = torch.cuda.current_stream(self.device)
         chunks = list(range(0, n, sam_chunk))
         if self.serial:
-            det_stream, sam_streams = main, [main] * len(chunks)
+            det_stream, emb_stream, sam_streams = main, main, [main] * len(chunks)
         else:
-            pool = self._streams(1 + len(chunks))
-            det_stream, sam_streams = pool[0], pool[1:]
+            pool = self._streams(2 + len(chunks))
+            det_stream, emb_stream, sam_streams = pool[0], pool[1], pool[2:]
             for st in pool:
                 st.wait_stream(main)  # frames were produced on the caller's stream
         with torch.cuda.stream(det_stream):
             boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf)
+        with torch.cuda.stream(emb_stream):
             emb = self.dino.embed_frames(frames)
         masks, stats, ious = [], [], []
         for i, st in zip(chunks, sam_streams):  # Hiera activations are ~100 MB/frame: a chunk bounds the live set
@@ -70,7 +71,7 @@ class FusedExtractor:
             masks.append(d["mask"])
             stats.append(d["stats"])
             ious.append(d["iou"])
-        for st in set(sam_streams + [det_stream]):
+        for st in set(sam_streams + [det_stream, emb_stream]):
             if st is not main:
                 main.wait_stream(st)
         cat = (lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, 0))
