@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=32, help="1080p frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=64, help="1080p frames per GPU per step")
     ap.add_argument("--sam-chunk", type=int, default=16, help="frames per SAM encoder pass (each pass runs on its own HIP stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
