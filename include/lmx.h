@@ -205,6 +205,16 @@ int lmx_k_detect_decode(const float* head, int64_t ldh, float* pred, int n, int 
 int lmx_k_scale_boxes(float* boxes, int total, float padx, float pady, float gain, float w, float h,
                       lmx_stream_t stream);
 
+/* Pose head post-processing for the detections lmx_k_nms kept (ultralytics Pose.kpts_decode + ops.scale_coords +
+ * clip_coords; the YOLOv8-pose consumer is services/tleap-pipeline/app/main.py:142-163, `result.keypoints[j].data`).
+ * raw0..2: the three levels' cv4 outputs, f32 [n][h_l][w_l][ldk] (ldk >= K*ndim); hw = {h0,w0,h1,w1,h2,w2} and strides[3]
+ * are HOST arrays; src / counts are lmx_k_nms's device outputs (anchor index per kept detection, detections per image).
+ * out f32 [n][max_det][K][ndim]: x, y in frame pixels ((v*2 + cell)*stride, minus the UNROUNDED letterbox padding,
+ * / gain, clipped to [0,w] x [0,h]) and sigmoid(visibility) when ndim == 3; rows >= counts[b] are zero. */
+int lmx_k_pose_gather(const float* raw0, const float* raw1, const float* raw2, int64_t ldk, const int32_t* hw,
+                      const float* strides, const int32_t* src, const int32_t* counts, int n, int max_det, int K, int ndim,
+                      float padx, float pady, float gain, float w, float h, float* out, lmx_stream_t stream);
+
 /* ---- SAM / Hiera non-GEMM pieces ------------------------------------------------------------------------ */
 /* K9+K10: im2col of the Hiera patch-embed conv (k7 s4 p3, TF sam2 :120-136) fused with SamPredictor's
  * normalisation and zero padding: img u8 [n][rh][rw][3] (the PIL-resized frame) sits at the top-left of an

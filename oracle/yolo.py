@@ -59,8 +59,10 @@ def _fused_conv(sd, name, x, k, s, act=True):
     return F.silu(y) if act else y
 
 
-def model_forward(scale, nc, sd, x, emulate_f16=False):
+def model_forward(scale, nc, sd, x, emulate_f16=False, kpt_shape=None):
     """x f32 [n,3,H,W] in [0,1] -> pred f32 [n, 4+nc, A] exactly as Detect returns it in eval mode (xywh | sigmoid cls).
+    With kpt_shape=(K, ndim) the head is Pose (yolov8-pose.yaml; the tleap-pipeline consumer,
+    services/tleap-pipeline/app/main.py:142-163): pred is [n, 4+nc+K*ndim, A] with the decoded keypoints appended.
 
     emulate_f16=True is a SECOND checker, not the parity target: the same fp32 arithmetic with weights and every
     stored activation rounded to half precision where the HIP path stores f16.  It separates "the kernels compute
@@ -69,12 +71,12 @@ def model_forward(scale, nc, sd, x, emulate_f16=False):
     global _EMULATE_F16
     _EMULATE_F16 = bool(emulate_f16)
     try:
-        return _model_forward(scale, nc, sd, x)
+        return _model_forward(scale, nc, sd, x, kpt_shape)
     finally:
         _EMULATE_F16 = False
 
 
-def _model_forward(scale, nc, sd, x):
+def _model_forward(scale, nc, sd, x, kpt_shape=None):
     depth, width, max_ch = _SCALES[scale]
 
     def ch(c):
@@ -138,6 +140,23 @@ def _model_forward(scale, nc, sd, x):
             x2y2 = anchors.unsqueeze(0) + rb
             dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * strides
             y = torch.cat((dbox, cls.sigmoid()), 1)
+            if kpt_shape is not None:
+                # Pose head (ultralytics nn/modules/head.py Pose): cv4 = Conv(x,c4,3) -> Conv(c4,c4,3) -> Conv2d(c4,nk,1),
+                # c4 = max(ch[0] // 4, nk); kpts_decode: xy = (v * 2 + (anchor - 0.5)) * stride, visibility = sigmoid
+                nkpt, ndim = kpt_shape
+                nk = nkpt * ndim
+                ks = []
+                for l, f in enumerate(feats):
+                    k = _q(_fused_conv(sd, p + f".cv4.{l}.0", f, 3, 1))
+                    k = _q(_fused_conv(sd, p + f".cv4.{l}.1", k, 3, 1))
+                    k = F.conv2d(k, _q(_t(sd, p + f".cv4.{l}.2.weight")), _t(sd, p + f".cv4.{l}.2.bias"))
+                    ks.append(k.view(bsz, nk, -1))
+                kp = torch.cat(ks, -1).clone()
+                if ndim == 3:
+                    kp[:, 2::3] = kp[:, 2::3].sigmoid()
+                kp[:, 0::ndim] = (kp[:, 0::ndim] * 2.0 + (anchors[0] - 0.5)) * strides
+                kp[:, 1::ndim] = (kp[:, 1::ndim] * 2.0 + (anchors[1] - 0.5)) * strides
+                y = torch.cat((y, kp), 1)
         outs.append(y)
     return outs[-1]
 
@@ -207,6 +226,38 @@ def scale_boxes(img1_shape, boxes, img0_shape):
     return b
 
 
+def scale_coords(img1_shape, coords, img0_shape):
+    """ultralytics.utils.ops.scale_coords + clip_coords on [..., (x, y, ...)] keypoints: unlike scale_boxes the padding is
+    NOT rounded."""
+    gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+    padx = (img1_shape[1] - img0_shape[1] * gain) / 2
+    pady = (img1_shape[0] - img0_shape[0] * gain) / 2
+    c = np.array(coords, np.float32, copy=True)
+    c[..., 0] -= np.float32(padx)
+    c[..., 1] -= np.float32(pady)
+    c[..., 0] /= np.float32(gain)
+    c[..., 1] /= np.float32(gain)
+    c[..., 0] = np.clip(c[..., 0], 0, np.float32(img0_shape[1]))
+    c[..., 1] = np.clip(c[..., 1], 0, np.float32(img0_shape[0]))
+    return c
+
+
+def predict_pose(scale, nc, kpt_shape, sd, frame_bgr, conf=0.25, iou=0.7, max_det=300, imgsz=640, emulate_f16=False):
+    """Pose model on one frame (what tleap's `self.model(frame, verbose=False, conf=0.3)` returns per detection):
+    -> dict(boxes [k,4], scores, cls, src, keypoints [k, K, ndim] in frame pixels)."""
+    lb = letterbox(frame_bgr, imgsz)
+    x = torch.from_numpy(np.ascontiguousarray(lb[:, :, ::-1].transpose(2, 0, 1))).float() / 255
+    with torch.no_grad():
+        full = model_forward(scale, nc, sd, x[None], emulate_f16, kpt_shape)[0].transpose(0, 1).contiguous().numpy()
+    pred, kp = full[:, :4 + nc], full[:, 4 + nc:]
+    boxes, scores, cls, src = ONMS.non_max_suppression(pred, conf, iou, max_det)  # the keypoints ride along by anchor index
+    kpts = kp[src].reshape(len(src), kpt_shape[0], kpt_shape[1]) if len(src) else np.zeros((0,) + tuple(kpt_shape), np.float32)
+    if len(boxes):
+        boxes = scale_boxes(lb.shape[:2], boxes, frame_bgr.shape[:2])
+        kpts = scale_coords(lb.shape[:2], kpts, frame_bgr.shape[:2])
+    return dict(boxes=boxes, scores=scores, cls=cls, src=src, keypoints=kpts, pred=pred, kpt_raw=kp, lb_shape=lb.shape[:2])
+
+
 def predict(scale, nc, sd, frame_bgr, conf=0.25, iou=0.7, max_det=300, imgsz=640, emulate_f16=False):
     """One frame, like the service's call: -> dict(boxes [k,4] xyxy frame px, scores, cls, src, pred [A,4+nc], lb shape)."""
     lb = letterbox(frame_bgr, imgsz)
@@ -218,7 +269,7 @@ def predict(scale, nc, sd, frame_bgr, conf=0.25, iou=0.7, max_det=300, imgsz=640
     return dict(boxes=boxes, scores=scores, cls=cls, src=src, pred=pred, lb_shape=lb.shape[:2])
 
 
-def calibrate_bn(scale, nc, sd, x):
+def calibrate_bn(scale, nc, sd, x, kpt_shape=None):
     """Synthetic-weight hygiene (not part of the reference): random Conv+SiLU stacks either collapse or overflow f16
     after ~60 layers, which a trained network avoids through BatchNorm.  This walks the model once on the batch ``x``
     and sets every BatchNorm's running_mean/var to the batch statistics of its conv output (what BN training mode
@@ -243,7 +294,7 @@ def calibrate_bn(scale, nc, sd, x):
     _fused_conv = conv_cal
     try:
         with torch.no_grad():
-            model_forward(scale, nc, sd, x)
+            model_forward(scale, nc, sd, x, kpt_shape=kpt_shape)
     finally:
         _fused_conv = saved
     return stats

@@ -93,6 +93,32 @@ def make_yolo(scale, seed, calib_clip, frames_spec):
     np.savez_compressed(os.path.join(HERE, f"yolov8{scale}_det_w{seed}.npz"), **out)
 
 
+def make_yolo_pose(scale, seed, calib_clip, frames_spec, kpt_shape=(17, 3), conf=0.05):
+    """YOLOv8-pose (the tleap-pipeline consumer): BN calibration statistics for the pose variant (nc = 1 changes the class
+    branch width, cv4 is new) + the fp32 oracle's detections and keypoints.  ORACLE outputs (parity unpinned)."""
+    from lmx import yolo
+    from oracle import yolo as OY
+
+    cfg = yolo.YoloConfig(scale, nc=1, kpt_shape=kpt_shape)
+    sd = yolo.synthetic_state_dict(cfg, seed)
+    calib = [synth.synth_frame(calib_clip, i) for i in (10, 90)]
+    x = torch.stack([torch.from_numpy(np.ascontiguousarray(OY.letterbox(f)[:, :, ::-1].transpose(2, 0, 1))).float() / 255
+                     for f in calib])
+    stats = OY.calibrate_bn(scale, cfg.nc, sd, x, kpt_shape=kpt_shape)
+    bn_path = os.path.join(HERE, f"yolov8{scale}-pose_bn_w{seed}.npz")
+    np.savez(bn_path, **stats)
+    sd = yolo.synthetic_state_dict(cfg, seed, bn_path)
+    out = {"weight_seed": seed, "frames": np.asarray(frames_spec), "conf": conf}
+    for j, (cs, fi) in enumerate(frames_spec):
+        r = OY.predict_pose(scale, cfg.nc, kpt_shape, sd, synth.synth_frame(cs, fi), conf=conf)
+        out[f"f{j}_boxes"], out[f"f{j}_scores"], out[f"f{j}_src"] = r["boxes"], r["scores"], r["src"]
+        out[f"f{j}_keypoints"] = r["keypoints"]
+        out[f"f{j}_kpt_raw_sample"] = r["kpt_raw"][::97].copy()
+        print(f"yolov8{scale}-pose frame {cs}/{fi}: {len(r['src'])} detections at conf {conf}, max score "
+              f"{float(r['pred'][:, 4].max()):.3f}")
+    np.savez_compressed(os.path.join(HERE, f"yolov8{scale}-pose_det_w{seed}.npz"), **out)
+
+
 def make_hiera(seed, clip_seed, frame_ids):
     """fp32 oracle (oracle.hiera, pinned to transformers' Sam2VisionModel by tests/test_oracle_hiera.py) on raw frames."""
     from lmx import sam
@@ -116,8 +142,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "hiera":
         make_hiera(5, 6, [20])
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pose":
+        make_yolo_pose("n", 7, 2, [(3, 40), (2, 50)])
+        sys.exit(0)
     make_yolo("n", 7, 2, [(3, 40), (2, 50), (4, 0)])
     make_yolo("l", 7, 2, [(3, 40), (2, 50)])
+    make_yolo_pose("n", 7, 2, [(3, 40), (2, 50)])
     torch.manual_seed(0)
     make_dino("dinov3_vitl16_w3", dino.dinov3_vitl16(), 3, [0, 75, 149], clip_seed=4)
     make_dino("dinov2_base_w4", dino.dinov2_base(), 4, [0, 30], clip_seed=5)

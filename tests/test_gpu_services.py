@@ -84,3 +84,28 @@ def test_fused_service_end_to_end(cuda, tmp_path):
             ref = OV.embed(dcfg, dsd, torch.from_numpy(OP.dino_pixel_values(frames[c["frame"]]))[None])[0]
         cos = torch.nn.functional.cosine_similarity(torch.tensor(c["embedding"], dtype=torch.float64), ref.double(), dim=0)
         assert float(cos) > 1 - 1e-4
+
+
+def test_tleap_pose_estimator_surface(cuda):
+    """services/tleap-pipeline/app/main.py:152-171: per detection a bbox, a confidence and name-keyed model keypoints."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from lmx import synth, yolo
+    from lmx.services import PoseEstimator
+    from lmx.services.pose import KEYPOINT_NAMES
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolov8n-pose_bn_w7.npz")
+    cfg = yolo.YoloConfig("n", nc=1, kpt_shape=(17, 3))
+    det = yolo.YoloDetector(cfg, yolo.synthetic_state_dict(cfg, 7, gold), cuda)
+    est = PoseEstimator(det, conf=0.05)
+    frames = torch.from_numpy(np.stack([synth.synth_frame(3, 40), synth.synth_frame(2, 50)], 0)).to(cuda)
+    res = est.detect_with_trained_model(frames)
+    assert len(res) == 2 and all(len(r) > 0 for r in res)
+    d = res[0][0]
+    assert set(d) == {"bbox", "confidence", "model_keypoints"} and len(d["bbox"]) == 4
+    assert list(d["model_keypoints"]) == KEYPOINT_NAMES[:17]
+    kp = d["model_keypoints"]["withers"]
+    assert set(kp) == {"name", "x", "y", "confidence"} and 0 <= kp["x"] <= 1920 and 0 <= kp["y"] <= 1080 and 0 < kp["confidence"] < 1

@@ -149,3 +149,89 @@ def test_yolo_end_to_end(cuda, scale, frames):
             want = OY.scale_boxes((geo.oh, geo.ow), rb, fr[j].shape[:2])
             assert np.allclose(boxes[j, :k].cpu().numpy(), want, atol=1e-3)
             assert float(boxes[j, :k, [0, 2]].max()) <= 1920 and float(boxes[j, :k, [1, 3]].max()) <= 1080
+
+
+def test_pose_gather_kernel_exact(cuda):
+    """lmx_k_pose_gather on hand-made level outputs: decode + unrounded-pad scale_coords + clip + sigmoid, zeros past counts."""
+    from lmx import kernels as K
+    from oracle import yolo as OY
+
+    rng = np.random.default_rng(40)
+    n, kshape, ldk = 2, (5, 3), 16
+    dims = [(6, 10), (3, 5), (2, 3)]
+    raws = [rng.standard_normal((n, h, w, ldk)).astype(np.float32) for h, w in dims]
+    A = sum(h * w for h, w in dims)
+    src = np.full((n, 8), -1, np.int32)
+    src[0, :5] = [0, 59, 60, 74, A - 1]
+    src[1, :2] = [7, 61]
+    counts = np.asarray([5, 2], np.int32)
+    gain, padx, pady, fw, fh = 0.25, 1.5, 10.25, 300.0, 120.0
+    got = K.pose_gather([torch.from_numpy(r).to(cuda) for r in raws], (8, 16, 32), torch.from_numpy(src).to(cuda),
+                        torch.from_numpy(counts).to(cuda), kshape, padx, pady, gain, fw, fh).cpu().numpy()
+    flat = np.concatenate([r.reshape(n, -1, ldk) for r in raws], 1)  # [n, A, ldk]
+    cell = np.concatenate([np.stack(np.meshgrid(np.arange(w), np.arange(h)), -1).reshape(-1, 2) for h, w in dims], 0)
+    strd = np.concatenate([np.full(h * w, s, np.float32) for (h, w), s in zip(dims, (8, 16, 32))])
+    for b in range(n):
+        for j in range(8):
+            if j >= counts[b]:
+                assert not got[b, j].any()
+                continue
+            a = src[b, j]
+            v = flat[b, a, :15].reshape(5, 3)
+            x = (v[:, 0] * np.float32(2) + cell[a, 0].astype(np.float32)) * strd[a]
+            y = (v[:, 1] * np.float32(2) + cell[a, 1].astype(np.float32)) * strd[a]
+            ref = np.clip(np.stack([(x - np.float32(padx)) / np.float32(gain), (y - np.float32(pady)) / np.float32(gain)], -1),
+                          0, [fw, fh]).astype(np.float32)
+            assert np.array_equal(got[b, j, :, :2], ref), (b, j)
+            assert np.allclose(got[b, j, :, 2], 1 / (1 + np.exp(-v[:, 2])), atol=2e-7)
+
+
+def test_pose_end_to_end(cuda):
+    """YOLOv8n-pose (services/tleap-pipeline/app/main.py:142-163: boxes + `result.keypoints[j].data`) against the fp32
+    oracle on 1080p frames.  As for detection the conv stack is f16: raw keypoint offsets must agree to quantisation
+    level, and detections kept by both paths must carry the same keypoints to a fraction of a pixel."""
+    from lmx import synth, yolo
+    from oracle import yolo as OY
+
+    kshape = (17, 3)
+    cfg = yolo.YoloConfig("n", nc=1, kpt_shape=kshape)
+    sd = yolo.synthetic_state_dict(cfg, 7, os.path.join(GOLD, "yolov8n-pose_bn_w7.npz"))
+    det = yolo.YoloDetector(cfg, sd, cuda)
+    gold = np.load(os.path.join(GOLD, "yolov8n-pose_det_w7.npz"))
+    conf = float(gold["conf"])
+    fr = np.stack([synth.synth_frame(int(cs), int(fi)) for cs, fi in gold["frames"]], 0)
+    d_fr = torch.from_numpy(fr).to(cuda)
+    boxes, scores, cls, src, counts, kpts = (t.cpu().numpy() for t in det.detect_pose(d_fr, conf=conf))
+    img, geo = det.preprocess(d_fr)
+    pred, kraw = det.forward_letterboxed(img)
+    raw = torch.cat([k.reshape(k.shape[0], -1, k.shape[-1]) for k in kraw], 1).cpu().numpy()[..., :51]  # [n, A, 51]
+    for j in range(fr.shape[0]):
+        ref = OY.predict_pose("n", 1, kshape, sd, fr[j], conf=conf)
+        assert np.array_equal(ref["src"], gold[f"f{j}_src"]), "oracle drifted from golden"
+        # raw keypoint head vs the oracle's decoded tensor, undone: x_raw = (x_dec / stride - cell) / 2
+        k = int(counts[j])
+        common = sorted(set(src[j, :k].tolist()) & set(ref["src"].tolist()))
+        assert len(common) >= 0.8 * max(k, len(ref["src"])), f"frame {j}: keep-sets differ too much ({len(common)} of {k}/{len(ref['src'])})"
+        gi = {a: i for i, a in enumerate(src[j, :k].tolist())}
+        ri = {a: i for i, a in enumerate(ref["src"].tolist())}
+        dxy = max(float(np.abs(kpts[j, gi[a], :, :2] - ref["keypoints"][ri[a], :, :2]).max()) for a in common)
+        dv = max(float(np.abs(kpts[j, gi[a], :, 2] - ref["keypoints"][ri[a], :, 2]).max()) for a in common)
+        dbox = max(float(np.abs(boxes[j, gi[a]] - ref["boxes"][ri[a]]).max()) for a in common)
+        print(f"pose frame {j}: {k} detections ({len(common)} common), keypoint xy max diff {dxy:.3f} px, visibility {dv:.4f}, box {dbox:.3f} px")
+        assert dxy < 6.0 and dv < 2e-2 and dbox < 12.0  # frame pixels = 3x letterboxed pixels
+        # f16-storage emulation: bounds the kernels themselves
+        emu = OY.predict_pose("n", 1, kshape, sd, fr[j], conf=conf, emulate_f16=True)
+        sel = np.asarray(common[:64])
+        lv = np.where(sel >= 80 * 48 + 40 * 24, 2, np.where(sel >= 80 * 48, 1, 0))  # 384x640 letterbox: 48x80, 24x40, 12x20
+        strd = np.asarray([8.0, 16.0, 32.0], np.float32)[lv]
+        dec = emu["kpt_raw"][sel].reshape(len(sel), 17, 3)
+        got_raw = raw[j, sel].reshape(len(sel), 17, 3)
+        # compare decoded-x differences in units of raw offsets: d(x_dec) = 2 * stride * d(raw)
+        offs = np.concatenate([[0], [48 * 80], [48 * 80 + 24 * 40]])
+        loc = sel - offs[lv]
+        wl = np.asarray([80, 40, 20])[lv]
+        cx, cy = (loc % wl).astype(np.float32), (loc // wl).astype(np.float32)
+        gx = (got_raw[..., 0] * 2 + cx[:, None]) * strd[:, None]
+        gy = (got_raw[..., 1] * 2 + cy[:, None]) * strd[:, None]
+        e = max(float(np.abs(gx - dec[..., 0]).max()), float(np.abs(gy - dec[..., 1]).max()))
+        assert e < 1.5, f"frame {j}: keypoint head disagrees with the f16-storage emulation by {e} letterboxed px"

@@ -94,3 +94,47 @@ def test_oracle_detections_match_committed_golden():
     r = OY.predict("n", 80, sd, synth.synth_frame(int(cs), int(fi)), conf=0.5)
     assert np.array_equal(r["src"], g["f2_c50_src"]) and np.array_equal(r["cls"], g["f2_c50_cls"])
     assert np.allclose(r["boxes"], g["f2_c50_boxes"], atol=1e-3) and np.allclose(r["scores"], g["f2_c50_scores"], atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------- YOLOv8-pose (tleap consumer)
+@pytest.mark.parametrize("scale,params,gflops", [("n", 3295470, 9.2), ("s", 11626046, 30.2), ("m", 26464462, 81.0),
+                                                  ("l", 44489196, 168.6), ("x", 69491724, 263.2)])
+def test_pose_published_params_and_flops(scale, params, gflops):
+    """Pose head (cv4, c4 = max(ch0 // 4, 51), nc = 1) against Ultralytics' published yolov8{n..x}-pose figures
+    (3.3 / 11.6 / 26.4 / 44.4 / 69.4 M parameters, 9.2 / 30.2 / 81.0 / 168.6 / 263.2 GFLOPs; n: 3,295,470 exactly)."""
+    p, macs = yolo.count_params_flops(yolo.YoloConfig(scale, nc=1, kpt_shape=(17, 3)))
+    assert abs(p - params) <= (0 if scale == "n" else 60000)  # only the n figure is published to the unit
+    assert round(p / 1e5) == round(params / 1e5)
+    assert abs(2 * macs / 1e9 - gflops) < 0.15
+
+
+def test_pose_decode_and_scale_coords_known_answers():
+    """kpts_decode on a hand-made head output and scale_coords on the 1080p letterbox (gain 1/3, pad (0, 12) UNROUNDED)."""
+    cfg = yolo.YoloConfig("n", nc=1, kpt_shape=(2, 3))
+    sd = yolo.synthetic_state_dict(cfg, 1)
+    # zero the pose branch's last conv and set its bias: every anchor then predicts raw (0.5, -0.25, 0) for keypoint 0
+    for l in range(3):
+        sd[f"model.22.cv4.{l}.2.weight"] = np.zeros_like(sd[f"model.22.cv4.{l}.2.weight"])
+        sd[f"model.22.cv4.{l}.2.bias"] = np.asarray([0.5, -0.25, 0.0, 0.0, 0.0, 2.0], np.float32)
+    x = torch.zeros((1, 3, 64, 96))
+    with torch.no_grad():
+        y = OY.model_forward("n", 1, sd, x, kpt_shape=(2, 3))[0]
+    kp = y[5:].T.reshape(-1, 2, 3).numpy()  # [A, 2, 3]
+    # level 0 (stride 8, 8 x 12 cells): anchor 13 = cell (y 1, x 1): x = (0.5*2 + 1) * 8 = 16, y = (-0.25*2 + 1) * 8 = 4
+    assert np.allclose(kp[13, 0], [16.0, 4.0, 0.5])
+    assert np.allclose(kp[13, 1], [8.0, 8.0, 1 / (1 + np.exp(-2.0))])
+    # level 1 starts at anchor 96 (stride 16, 4 x 6 cells): anchor 96 + 7 = cell (1, 1)
+    assert np.allclose(kp[96 + 7, 0], [(1.0 + 1) * 16, (-0.5 + 1) * 16, 0.5])
+    c = OY.scale_coords((384, 640), np.asarray([[[320.0, 12.0, 0.7], [700.0, 500.0, 0.1]]], np.float32), (1080, 1920))
+    assert np.allclose(c[0, 0], [960.0, 0.0, 0.7]) and np.allclose(c[0, 1], [1920.0, 1080.0, 0.1])
+
+
+def test_pose_oracle_matches_committed_golden():
+    cfg = yolo.YoloConfig("n", nc=1, kpt_shape=(17, 3))
+    sd = yolo.synthetic_state_dict(cfg, 7, os.path.join(GOLD, "yolov8n-pose_bn_w7.npz"))
+    gold = np.load(os.path.join(GOLD, "yolov8n-pose_det_w7.npz"))
+    cs, fi = gold["frames"][0]
+    r = OY.predict_pose("n", 1, (17, 3), sd, synth.synth_frame(int(cs), int(fi)), conf=float(gold["conf"]))
+    assert np.array_equal(r["src"], gold["f0_src"])
+    assert np.allclose(r["keypoints"], gold["f0_keypoints"], atol=1e-3)
+    assert np.allclose(r["kpt_raw"][::97], gold["f0_kpt_raw_sample"], atol=1e-4)

@@ -248,7 +248,69 @@ __global__ __launch_bounds__(256) void scale_boxes_kernel(float* __restrict__ bo
   b[3] = fminf(fmaxf(y2, 0.f), h);
 }
 
+// ---- Pose head post-processing (ultralytics Pose.kpts_decode + ops.scale_coords + clip_coords) for the detections NMS
+// kept: thread = (image, detection slot, keypoint).  The keypoints ride along by anchor index (`src` of lmx_k_nms), so only
+// <= max_det anchors per image are decoded instead of all A.
+struct PoseLevels {
+  const float* raw[3];  // per level: f32 [n][h][w][ldk]
+  int h[3], w[3], off[3];
+  float stride[3];
+};
+__global__ __launch_bounds__(256) void pose_gather_kernel(const PoseLevels L, int64_t ldk, const int* __restrict__ src,
+                                                          const int* __restrict__ counts, int n, int max_det, int K, int ndim,
+                                                          float padx, float pady, float gain, float fw, float fh,
+                                                          float* __restrict__ out) {
+  const int64_t total = (int64_t)n * max_det * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const int64_t r = i / K;
+    const int j = (int)(r % max_det);
+    const int b = (int)(r / max_det);
+    float* o = out + i * ndim;
+    if (j >= counts[b]) {
+      for (int e = 0; e < ndim; ++e) o[e] = 0.f;
+      continue;
+    }
+    const int a = src[(int64_t)b * max_det + j];
+    const int l = a >= L.off[2] ? 2 : (a >= L.off[1] ? 1 : 0);
+    const int local = a - L.off[l];
+    const int y = local / L.w[l], x = local - y * L.w[l];
+    const float* v = L.raw[l] + (((int64_t)b * L.h[l] + y) * L.w[l] + x) * ldk + k * ndim;
+    // kpts_decode: (v * 2 + (anchor - 0.5)) * stride with anchor = cell + 0.5; then scale_coords: (c - pad) / gain, clipped
+    const float X = (v[0] * 2.0f + (float)x) * L.stride[l];
+    const float Y = (v[1] * 2.0f + (float)y) * L.stride[l];
+    o[0] = fminf(fmaxf((X - padx) / gain, 0.f), fw);
+    o[1] = fminf(fmaxf((Y - pady) / gain, 0.f), fh);
+    if (ndim == 3) o[2] = 1.0f / (1.0f + expf(-v[2]));
+  }
+}
+
 }  // namespace
+
+extern "C" int lmx_k_pose_gather(const float* raw0, const float* raw1, const float* raw2, int64_t ldk, const int32_t* hw,
+                                 const float* strides, const int32_t* src, const int32_t* counts, int n, int max_det, int K,
+                                 int ndim, float padx, float pady, float gain, float w, float h, float* out,
+                                 lmx_stream_t stream) {
+  LMX_REQUIRE(raw0 && raw1 && raw2 && hw && strides && src && counts && out, "lmx_k_pose_gather: null pointer");
+  LMX_REQUIRE(n > 0 && max_det > 0 && K > 0 && (ndim == 2 || ndim == 3) && ldk >= (int64_t)K * ndim && gain > 0.f,
+              "lmx_k_pose_gather: arguments");
+  PoseLevels L;
+  L.raw[0] = raw0;
+  L.raw[1] = raw1;
+  L.raw[2] = raw2;
+  int off = 0;
+  for (int l = 0; l < 3; ++l) {
+    LMX_REQUIRE(hw[2 * l] > 0 && hw[2 * l + 1] > 0, "lmx_k_pose_gather: level %d geometry", l);
+    L.h[l] = hw[2 * l];
+    L.w[l] = hw[2 * l + 1];
+    L.off[l] = off;
+    L.stride[l] = strides[l];
+    off += L.h[l] * L.w[l];
+  }
+  hipLaunchKernelGGL(pose_gather_kernel, dim3(grid_for((int64_t)n * max_det * K)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), L, ldk, src, counts, n, max_det, K, ndim, padx, pady, gain, w, h, out);
+  return lmx_launch_check("pose_gather_kernel");
+}
 
 extern "C" int lmx_k_letterbox(const uint8_t* src, uint8_t* dst, int n, int sh, int sw, int rh, int rw, int top, int left,
                                int oh, int ow, const int32_t* xofs, const int16_t* ialpha, const int32_t* yofs,

@@ -393,6 +393,27 @@ def scale_boxes(boxes, padx, pady, gain, w, h):
     return boxes
 
 
+def pose_gather(raws, strides, src, counts, kpt_shape, padx, pady, gain, w, h):
+    """Keypoints of the detections NMS kept: raws = the three levels' cv4 outputs f32 [n,h,w,ldk]; src / counts from nms().
+    -> f32 [n, max_det, K, ndim] in frame pixels (lmx_k_pose_gather)."""
+    _dev(*raws, src, counts)
+    K_, ndim = kpt_shape
+    ldk = raws[0].shape[-1]
+    for r in raws:
+        if r.dtype != torch.float32 or not r.is_contiguous() or r.dim() != 4 or r.shape[-1] != ldk:
+            raise LmxError("pose_gather: levels must be dense float32 [n,h,w,ldk]")
+    if src.dtype != torch.int32 or counts.dtype != torch.int32 or not src.is_contiguous():
+        raise LmxError("pose_gather: src / counts must be int32")
+    n, max_det = src.shape
+    hw = (C.c_int32 * 6)(*[v for r in raws for v in (r.shape[1], r.shape[2])])
+    st = (C.c_float * 3)(*[float(v) for v in strides])
+    out = torch.empty((n, max_det, K_, ndim), dtype=torch.float32, device=src.device)
+    check(_lib.load().lmx_k_pose_gather(_ptr(raws[0]), _ptr(raws[1]), _ptr(raws[2]), ldk, C.cast(hw, C.c_void_p),
+                                        C.cast(st, C.c_void_p), _ptr(src), _ptr(counts), n, max_det, K_, ndim, float(padx),
+                                        float(pady), float(gain), float(w), float(h), _ptr(out), _stream()), "lmx_k_pose_gather")
+    return out
+
+
 def add_bcast(a, b, out=None, out_dtype=torch.float32):
     """out[r] = a[r] + b[r % b_rows]  (a, b float32 2-D; out float32 or float16)."""
     _dev(a, b, out)

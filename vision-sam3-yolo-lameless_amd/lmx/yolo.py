@@ -42,6 +42,7 @@ class YoloConfig:
     scale: str = "l"
     nc: int = 80
     imgsz: int = 640
+    kpt_shape: tuple = None  # (K, ndim): Pose head (yolov8-pose.yaml) — the tleap-pipeline consumer, tleap main.py:142-163
 
     def ch(self, c):
         _, width, max_ch = SCALES[self.scale]
@@ -141,6 +142,14 @@ def param_spec(cfg):
                 _conv_spec(s, p + f".cv3.{l}.1", c3, c3, 3)
                 s[p + f".cv3.{l}.2.weight"] = ((cfg.nc, c3, 1, 1), "w")
                 s[p + f".cv3.{l}.2.bias"] = ((cfg.nc,), "clsb")
+            if cfg.kpt_shape is not None:  # Pose: cv4 = Conv(x,c4,3) -> Conv(c4,c4,3) -> Conv2d(c4,nk,1), c4 = max(ch[0]//4, nk)
+                nk = cfg.kpt_shape[0] * cfg.kpt_shape[1]
+                c4 = max(ch[0] // 4, nk)
+                for l, x in enumerate(ch):
+                    _conv_spec(s, p + f".cv4.{l}.0", x, c4, 3)
+                    _conv_spec(s, p + f".cv4.{l}.1", c4, c4, 3)
+                    s[p + f".cv4.{l}.2.weight"] = ((nk, c4, 1, 1), "w")
+                    s[p + f".cv4.{l}.2.bias"] = ((nk,), "b")
     return s
 
 
@@ -200,6 +209,10 @@ def count_params_flops(cfg, h=640, w=640):
             for x, j in zip(m["ch"], m["src"]):
                 px = res[j][0] * res[j][1]
                 macs += px * (9 * x * c2 + 9 * c2 * c2 + c2 * 64 + 9 * x * c3 + 9 * c3 * c3 + c3 * cfg.nc)
+                if cfg.kpt_shape is not None:
+                    nk = cfg.kpt_shape[0] * cfg.kpt_shape[1]
+                    c4 = max(m["ch"][0] // 4, nk)
+                    macs += px * (9 * x * c4 + 9 * c4 * c4 + c4 * nk)
         res[i] = hw
     return params, macs
 
@@ -258,6 +271,30 @@ class YoloDetector:
                             b = np.concatenate([b, np.zeros((self.nc_pad - cfg.nc,), np.float32)], 0)
                         self.w[p + f".{br}.{l}.2"] = (torch.from_numpy(np.ascontiguousarray(w)).to(dev).half().contiguous(),
                                                       torch.from_numpy(b).to(dev))
+                if cfg.kpt_shape is not None:
+                    # Pose branch: c4 = max(ch[0]//4, nk) is not a multiple of 8 in general (51 for 17x3 keypoints): zero-pad
+                    # the channels (SiLU(0) = 0, so padded channels stay zero through the branch)
+                    nk = cfg.kpt_shape[0] * cfg.kpt_shape[1]
+                    c4 = max(m["ch"][0] // 4, nk)
+                    c4p, self.nk_pad = (c4 + 7) // 8 * 8, (nk + 3) // 4 * 4
+
+                    def padded3(name, cin_pad, cout_pad):
+                        w, b = fold_bn(sd, name)
+                        wz = np.zeros((cout_pad, cin_pad, 3, 3), np.float32)
+                        wz[:w.shape[0], :w.shape[1]] = w
+                        bz = np.zeros((cout_pad,), np.float32)
+                        bz[:b.shape[0]] = b
+                        wp = np.transpose(wz, (0, 2, 3, 1)).reshape(cout_pad, -1)
+                        return (torch.from_numpy(np.ascontiguousarray(wp)).to(dev).half().contiguous(), torch.from_numpy(bz).to(dev))
+
+                    for l, x in enumerate(m["ch"]):
+                        self.w[p + f".cv4.{l}.0"] = padded3(p + f".cv4.{l}.0", x, c4p)
+                        self.w[p + f".cv4.{l}.1"] = padded3(p + f".cv4.{l}.1", c4p, c4p)
+                        wz = np.zeros((self.nk_pad, c4p), np.float32)
+                        wz[:nk, :c4] = sd[p + f".cv4.{l}.2.weight"][:, :, 0, 0]
+                        bz = np.zeros((self.nk_pad,), np.float32)
+                        bz[:nk] = sd[p + f".cv4.{l}.2.bias"]
+                        self.w[p + f".cv4.{l}.2"] = (torch.from_numpy(wz).to(dev).half().contiguous(), torch.from_numpy(bz).to(dev))
         self._tabs = {}
 
     # ---- network --------------------------------------------------------------------------------------------
@@ -326,6 +363,7 @@ class YoloDetector:
         A = H8 * W8 + H16 * W16 + H32 * W32
         pred = torch.empty((n, A, 4 + cfg.nc), dtype=torch.float32, device=dev)
         a_off = 0
+        kraw = []  # Pose: raw cv4 outputs per level, f32 [n,h,w,nk_pad]
         ldh = 64 + self.nc_pad
         for l, (feat, stride) in enumerate(((p3, 8), (p4, 16), (p5, 32))):
             p = f"model.22"
@@ -339,6 +377,12 @@ class YoloDetector:
             K.conv1x1(t, *self.w[p + f".cv3.{l}.2"], act=K.ACT_NONE, out=head[..., 64:])
             K.detect_decode(head, pred, cfg.nc, stride, a_off)
             a_off += h * w
+            if cfg.kpt_shape is not None:
+                t = K.conv3x3(feat, *self.w[p + f".cv4.{l}.0"], act=K.ACT_SILU)
+                t = K.conv3x3(t, *self.w[p + f".cv4.{l}.1"], act=K.ACT_SILU)
+                kraw.append(K.conv1x1(t, *self.w[p + f".cv4.{l}.2"], act=K.ACT_NONE, out_dtype=torch.float32))
+        if cfg.kpt_shape is not None:
+            return pred, kraw
         return pred
 
     # ---- pre / post ------------------------------------------------------------------------------------------
@@ -357,10 +401,26 @@ class YoloDetector:
         geo, tabs = self._letterbox_tables(sh, sw)
         return K.letterbox(frames_bgr, geo, tabs, swap_rb=True), geo
 
+    def detect_pose(self, frames_bgr, conf=0.25, iou=0.7, max_det=300):
+        """Pose models: detect() plus keypoints f32 [n, max_det, K, ndim] in FRAME pixels (x, y, sigmoid visibility)."""
+        if self.cfg.kpt_shape is None:
+            raise ValueError("detect_pose: the model has no Pose head (YoloConfig.kpt_shape)")
+        img, geo = self.preprocess(frames_bgr)
+        pred, kraw = self.forward_letterboxed(img)
+        boxes, scores, cls, src, counts = K.nms(pred, conf, iou, max_det)
+        K.scale_boxes(boxes, geo.pad_x, geo.pad_y, geo.gain, geo.sw, geo.sh)
+        # ops.scale_coords subtracts the UNROUNDED padding (scale_boxes rounds it like LetterBox does)
+        padx = (img.shape[2] - geo.sw * geo.gain) / 2
+        pady = (img.shape[1] - geo.sh * geo.gain) / 2
+        kpts = K.pose_gather(kraw, (8, 16, 32), src, counts, self.cfg.kpt_shape, padx, pady, geo.gain, geo.sw, geo.sh)
+        return boxes, scores, cls, src, counts, kpts
+
     def detect(self, frames_bgr, conf=0.25, iou=0.7, max_det=300):
         """u8 BGR [n,h,w,3] on device -> (boxes [n,max_det,4] xyxy in FRAME pixels, scores, cls, src, counts) on device."""
         img, geo = self.preprocess(frames_bgr)
         pred = self.forward_letterboxed(img)
+        if self.cfg.kpt_shape is not None:
+            pred = pred[0]
         boxes, scores, cls, src, counts = K.nms(pred, conf, iou, max_det)
         K.scale_boxes(boxes, geo.pad_x, geo.pad_y, geo.gain, geo.sw, geo.sh)
         return boxes, scores, cls, src, counts
