@@ -109,3 +109,34 @@ def test_tleap_pose_estimator_surface(cuda):
     assert list(d["model_keypoints"]) == KEYPOINT_NAMES[:17]
     kp = d["model_keypoints"]["withers"]
     assert set(kp) == {"name", "x", "y", "confidence"} and 0 <= kp["x"] <= 1920 and 0 <= kp["y"] <= 1080 and 0 < kp["confidence"] < 1
+
+
+def test_clip_curation_tracker(cuda):
+    """track_cow_through_video's per-frame records (clip-curation main.py:154-165) over a batch of frames, yolov8n."""
+    import os
+
+    import numpy as np
+    import torch
+
+    from lmx import synth, yolo
+    from lmx.services import CowTracker
+    from lmx.services.curation import best_detection
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolov8n_bn_w7.npz")
+    cfg = yolo.YoloConfig("n")
+    det = yolo.YoloDetector(cfg, yolo.synthetic_state_dict(cfg, 7, gold), cuda)
+    frames = torch.from_numpy(np.stack([synth.synth_frame(3, i) for i in (40, 41, 42)], 0)).to(cuda)
+    recs = CowTracker(det, conf=0.3, batch=2).track(frames, fps=30.0, first_frame=100)
+    assert [r["frame"] for r in recs] == [100, 101, 102] and abs(recs[1]["time"] - 101 / 30.0) < 1e-12
+    # same batches as the tracker: the GEMM dispatch depends on the row count (the 12x20 level of a 2-frame batch has
+    # M = 480 < 512 rows and takes the register-staged kernel), so another batching may differ in the last f32 bit of an
+    # accumulation — and a random 60-layer network amplifies that to a fraction of a pixel
+    for i0 in (0, 2):
+        boxes, scores, cls, _, counts = (t.cpu().numpy() for t in det.detect(frames[i0:i0 + 2], conf=0.3))
+        for b in range(boxes.shape[0]):
+            r = recs[i0 + b]
+            ref = best_detection(boxes[b], scores[b], cls[b], counts[b], 1080, 1920)
+            assert (r["detection"] is None) == (ref is None)
+            if ref is not None:
+                assert r["detection"]["bbox"] == ref["bbox"] and r["detection"]["area"] == ref["area"]
+    assert any(r["detection"] is not None for r in recs)

@@ -164,3 +164,22 @@ def test_fused_order(tmp_path):
     assert [p[0] for p in bus.published] == ["video.preprocessed", "pipeline.yolo", "pipeline.sam3", "pipeline.dinov3"]
     sam = json.load(open(tmp_path / "sam3" / "z_sam3.json"))
     assert all(sg["mask_available"] for sg in sam["segmentations"])  # YOLO ran first: no race
+
+
+def test_clip_curation_best_detection_rule():
+    """services/clip-curation/app/main.py:106-131: largest box that is a cow (COCO 19) or covers > 10 % of the frame."""
+    import numpy as np
+
+    from lmx.services.curation import best_detection
+
+    boxes = np.asarray([[0, 0, 100, 100], [10, 10, 500, 400], [0, 0, 1000, 700], [5, 5, 50, 60]], np.float32)
+    scores = np.asarray([0.9, 0.8, 0.4, 0.95], np.float32)
+    cls = np.asarray([19, 19, 3, 19], np.int32)
+    d = best_detection(boxes, scores, cls, 4, 1080, 1920)   # the non-cow box is 33 % of the frame and the largest
+    assert d["bbox"] == [0.0, 0.0, 1000.0, 700.0] and abs(d["confidence"] - 0.4) < 1e-6 and d["area"] == 700000.0
+    assert d["centroid"] == (500.0, 350.0)
+    d = best_detection(boxes, scores, cls, 2, 1080, 1920)   # only the first two rows are valid detections
+    assert d["bbox"] == [10.0, 10.0, 500.0, 400.0]
+    cls2 = np.asarray([3, 3, 3, 3], np.int32)
+    assert best_detection(boxes[:2], scores, cls2, 2, 1080, 1920) is None  # small non-cow boxes are ignored
+    assert best_detection(boxes, scores, cls, 0, 1080, 1920) is None

@@ -7,3 +7,4 @@ from .fused import FusedFeatureService  # noqa: F401
 from .sam3_pipeline import SAM3Pipeline  # noqa: F401
 from .yolo_pipeline import YOLOPipeline  # noqa: F401
 from .pose import PoseEstimator  # noqa: F401
+from .curation import CowTracker  # noqa: F401
