@@ -395,10 +395,21 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     case 'T': return launch2<256, 128, 64, 3, 0, 1>(d, st);  // staggered, 3 x 48 KB ring
     case 'U': return launch2<256, 128, 32, 3, 0, 1>(d, st);  // staggered, 3 x 24 KB ring, 2 blocks/CU
     case 'V': return launch2<256, 128, 32, 4, 0, 1>(d, st);  // staggered, 4 x 24 KB ring
+    case 'W': return launch2<256, 256, 32, 4, 0, 1>(d, st);  // staggered 256x256, 16 waves, 4 x 32 KB ring
+    case 'Y': return launch2<256, 256, 32, 3, 0, 1>(d, st);  // staggered 256x256, 3 x 32 KB ring
     default: {
       // measured on the model shapes (profiles/r01_gemm_variants.txt, r01_gemm_staggered_variants.txt): with K < ~1.8k the
       // per-tile prologue/epilogue dominates and two co-resident workgroups (C) hide it; long-K problems, and problems with
       // no more tiles than CUs, prefer the staggered schedule on the 3 x 48 KB ring (T), one workgroup per CU
+      // 256 x 256 tiles (staggered, 16 waves, 3 x 32 KB ring, one workgroup per CU) move a third fewer L2->LDS bytes per
+      // flop and win 13-24 % where the tile grid wastes little (profiles/r01_gemm_staggered_variants.txt): N a multiple of
+      // 256 (or >= 85 % of its last tile when K >= 896 amortises the waste), at least ~one tile per CU, and a last round of
+      // tiles that is not mostly empty
+      const int64_t nt256 = (d.N + 255) / 256, tiles256 = (int64_t)((d.M + 255) / 256) * nt256;
+      const double nfrac = (double)d.N / (double)(nt256 * 256);
+      const double q256 = (double)tiles256 / (double)(((tiles256 + 255) / 256) * 256);
+      if (d.K >= 448 && tiles256 >= 230 && q256 >= 0.75 && (d.K < 896 ? d.N % 256 == 0 : nfrac >= 0.85))
+        return launch2<256, 256, 32, 3, 0, 1>(d, st);
       const int64_t tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128);
       return (d.K >= 1792 || tiles <= 256) ? launch2<256, 128, 64, 3, 0, 1>(d, st) : launch2<256, 128, 32, 3, 0>(d, st);
     }
