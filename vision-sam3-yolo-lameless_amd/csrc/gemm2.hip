@@ -380,7 +380,14 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     const char* e = getenv("LMX_GEMM2_VARIANT");
     variant = e ? e[0] : 0;
   }
-  if (d.a_mode == 1) return launch2<256, 128, 32, 3, 1>(d, st);  // 3x3 convolution, Cin % 32 == 0 (checked by the caller)
+  if (d.a_mode == 1) {  // 3x3 convolution, Cin % 32 == 0 (checked by the caller)
+    static int conv_small = -1;
+    if (conv_small < 0) conv_small = getenv("LMX_GEMM2_CONV_SMALL") ? 1 : 0;
+    const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256);
+    const double q256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+    if (!conv_small && d.N % 256 == 0 && t256 >= 230 && q256 >= 0.75) return launch2<256, 256, 32, 3, 1, 1>(d, st);
+    return launch2<256, 128, 32, 3, 1>(d, st);
+  }
   switch (variant) {
     case 'A': return launch2<256, 128, 64, 3, 0>(d, st);
     case 'B': return launch2<128, 128, 64, 2, 0>(d, st);
