@@ -228,7 +228,10 @@ def _window_ref(x_q, x_k, x_v, Gh, Gw, ws, heads, hd, pad_k, pad_v, q_stride=1):
 
 
 @pytest.mark.parametrize("n,Gh,Gw,ws,heads,hd,qs", [(2, 16, 16, 8, 2, 56, 1), (1, 20, 20, 14, 4, 56, 1), (2, 12, 12, 4, 3, 64, 1),
-                                                    (1, 64, 64, 14, 2, 64, 1), (1, 16, 16, 8, 4, 56, 2), (1, 20, 20, 14, 2, 56, 2)])
+                                                    (1, 64, 64, 14, 2, 64, 1), (1, 16, 16, 8, 4, 56, 2), (1, 20, 20, 14, 2, 56, 2),
+                                                    # 4 x 4 windows take the one-wave-per-window kernel: padded grids, Q-pool
+                                                    # (4 queries), an item count that is not a multiple of 4
+                                                    (1, 12, 12, 4, 2, 56, 2), (2, 10, 10, 4, 5, 56, 1), (1, 8, 8, 4, 1, 32, 1)])
 def test_attention_window(cuda, n, Gh, Gw, ws, heads, hd, qs):
     from lmx import kernels as Kk
 

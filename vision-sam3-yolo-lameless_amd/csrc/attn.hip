@@ -389,6 +389,101 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
 }
 
 
+// ---- tiny sequences (Tq <= 16 and Tk <= 16: Hiera's 4 x 4 windows, 16 384 of them per image batch and head).
+// attn_kernel spends a 4-wave workgroup, a 64 x 64 LDS tile and a barrier on each (window, head) and uses 1/16 of its
+// MFMA work; here ONE WAVE owns an item and nothing is shared: Q and K fragments come straight from global memory (a lane's
+// 16 bytes are contiguous in both), V goes through a wave-private 2 KB LDS slice only to be read back transposed, one
+// 16 x 16 x 32 MFMA pair gives S^T, one per 16-wide d block gives O^T.  No barrier, 8 KB of LDS per workgroup.
+__global__ __launch_bounds__(256) void attn_small_kernel(const lmx_attn_desc p, const Geo geo, const int items) {
+  __shared__ __attribute__((aligned(16))) half_t Vs[4][16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= items) return;  // whole wave (items are per wave; there is no barrier in this kernel)
+  const int h = item % p.H, b = item / p.H;
+  const half_t* Q = reinterpret_cast<const half_t*>(p.Q);
+  const half_t* K = reinterpret_cast<const half_t*>(p.K);
+  const half_t* V = reinterpret_cast<const half_t*>(p.V);
+  const half_t* padk = reinterpret_cast<const half_t*>(p.pad_k);
+  const half_t* padv = reinterpret_cast<const half_t*>(p.pad_v);
+  const int hd = p.hd;
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // V: lane -> key row lane>>2, the two 16-byte chunks 2*(lane&3), +1 (branch-free loads, selected afterwards)
+  {
+    const int r = lane >> 2, c0 = (lane & 3) * 2;
+    const bool in = r < p.Tk;
+    const int64_t row = key_row(geo, b, in ? r : 0);
+    const bool pad = row < 0;
+    half_t* dst = &Vs[wave][r * 64];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = c0 + e, d = c * 8;
+      const bool ok = in && d < hd && (!pad || padv);
+      const half_t* vp = (in && d < hd) ? (pad ? (padv ? padv + (int64_t)h * hd + d : V) : V + row * p.ldv + (int64_t)h * hd + d) : V;
+      const half8_t vv = *reinterpret_cast<const half8_t*>(vp);
+      *reinterpret_cast<half8_t*>(dst + ((c ^ (r & 7)) << 3)) = ok ? vv : zero8;
+    }
+  }
+  // Q (B operand) and K (A operand) fragments: lane (fr, fg) holds row fr, features 32*ks + 8*fg .. +7
+  const int64_t qrow = fr < p.Tq ? query_row(geo, b, fr) : -1;
+  const bool kin = fr < p.Tk;
+  const int64_t krow = key_row(geo, b, kin ? fr : 0);
+  const bool kpad = krow < 0;
+  half8_t qf[2], kf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int d = ks * 32 + fg * 8;
+    const bool dq = qrow >= 0 && d < hd;
+    const half8_t qv = *reinterpret_cast<const half8_t*>(Q + (dq ? qrow * p.ldq + (int64_t)h * hd + d : 0));
+    qf[ks] = dq ? qv : zero8;
+    const bool dk = kin && d < hd;
+    const half_t* kp = dk ? (kpad ? (padk ? padk + (int64_t)h * hd + d : K) : K + krow * p.ldk + (int64_t)h * hd + d) : K;
+    const half8_t kv = *reinterpret_cast<const half8_t*>(kp);
+    kf[ks] = (dk && (!kpad || padk)) ? kv : zero8;
+  }
+  // S^T[key][query]: lane (fr = query, fg) holds keys 4*fg + i
+  f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+  sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], sacc, 0, 0, 0);
+  sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], sacc, 0, 0, 0);
+  const float sl2 = p.scale * 1.44269504088896340736f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (fg * 4 + i >= p.Tk) sacc[i] = -INFINITY;
+  float mx = fmaxf(fmaxf(sacc[0], sacc[1]), fmaxf(sacc[2], sacc[3]));
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mb = mx * sl2;
+  half8_t pf = zero8;  // k-slot 8*fg + j <-> key 4*fg + j for j < 4 (attn_kernel's permutation at ks = 0); slots j >= 4 are keys >= 16
+  float l = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const half_t e = (half_t)__builtin_amdgcn_exp2f(fmaf(sacc[i], sl2, -mb));
+    pf[i] = e;
+    l += (float)e;  // sums exactly what the PV MFMA sees
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  // O^T = V^T . P^T: V^T fragments by transposed reads of the wave's own slice (same addressing as attn_kernel, key rows 0..15)
+  const int q4 = fr >> 2, p4 = fr & 3;
+  const int r0 = fg * 4 + q4;
+  half_t* O = reinterpret_cast<half_t*>(p.O);
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const int chunk = db * 2 + (p4 >> 1);
+    const half4_t lo = lds_tr_read(&Vs[wave][r0 * 64 + ((chunk ^ (r0 & 7)) << 3) + (p4 & 1) * 4]);
+    const half8_t vf = {lo[0], lo[1], lo[2], lo[3], 0, 0, 0, 0};
+    f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
+    oacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc, 0, 0, 0);
+    const int d = db * 16 + fg * 4;
+    if (qrow >= 0 && d < hd) {
+      const half4_t o = {(half_t)(oacc[0] * inv), (half_t)(oacc[1] * inv), (half_t)(oacc[2] * inv), (half_t)(oacc[3] * inv)};
+      *reinterpret_cast<half4_t*>(O + qrow * p.ldo + (int64_t)h * hd + d) = o;
+    }
+  }
+}
+
 // thread = one (b, h, t): q row in registers, 2S dot products against the relative-position rows (L1/L2 resident).
 __global__ __launch_bounds__(256) void relpos_tables_kernel(const lmx_attn_desc p, const Geo geo, const float* __restrict__ rh,
                                                             const float* __restrict__ rw, int S, half_t* __restrict__ out) {
@@ -474,6 +569,12 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
+  if (d.Tq <= 16 && d.Tk <= 16 && !d.rel) {  // one wave per (batch | window, head)
+    const int64_t items = (int64_t)d.B * d.H;
+    LMX_REQUIRE(items < (1ll << 31), "lmx_k_attention: grid too large");
+    hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, d, g, (int)items);
+    return lmx_launch_check("attn_small_kernel");
+  }
   const bool big = d.Tq > 64;
   const int qtile = big ? 128 : 64;
   int nQT = (d.Tq + qtile - 1) / qtile;
