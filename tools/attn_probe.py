@@ -6,6 +6,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vision-sam3-yolo-lameless_amd")]
+from lmx import _lib  # noqa: E402
+if os.environ.get("LMX_DBG_LIB"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["LMX_DBG_LIB"])
 from lmx import kernels as K  # noqa: E402
 
 dev = torch.device("cuda:0")
