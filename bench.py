@@ -101,13 +101,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # LMX_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend — a single-GPU rehearsal of the multi-rank control
+    # flow (rendezvous, gather, barriers, max-over-ranks timing); never a measurement
+    rehearse = bool(os.environ.get("LMX_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from lmx import dist as ldist
     from lmx import kernels as K
@@ -162,7 +170,7 @@ def main():
     fx.serial = False
     log(f"roofline pass: {args.steps} serialized steps in {dt_serial:.3f}s")
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

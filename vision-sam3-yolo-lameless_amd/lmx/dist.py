@@ -18,10 +18,15 @@ def gather_frame_records(rec):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rec
     world = dist.get_world_size()
+    # gloo (CPU tests, single-GPU rehearsals of the multi-rank bench) gathers host tensors; nccl = RCCL gathers in place
+    via_host = dist.get_backend() == "gloo"
     out = {}
     for k, v in rec.items():
+        dev = v.device
         v = v.contiguous()
+        if via_host and dev.type != "cpu":
+            v = v.cpu()
         g = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
         dist.all_gather_into_tensor(g, v)
-        out[k] = g
+        out[k] = g.to(dev) if g.device != dev else g
     return out
