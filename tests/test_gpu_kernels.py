@@ -184,7 +184,9 @@ def _attn_ref(q, k, v, scale):
 
 # T >= 256 takes the LDS-DMA ring (attn.hip DMA path): ragged last tile, head-dim padding chunks, one / many key tiles
 @pytest.mark.parametrize("B,H,T,hd", [(2, 16, 201, 64), (3, 2, 64, 56), (1, 4, 300, 32), (2, 3, 16, 64), (1, 2, 1000, 56),
-                                      (2, 3, 257, 64), (3, 2, 256, 56), (1, 2, 4096, 56), (2, 1, 1153, 48)])
+                                      (2, 3, 257, 64), (3, 2, 256, 56), (1, 2, 4096, 56), (2, 1, 1153, 48),
+                                      # head dims 72..96 take the wide class (128-half LDS rows, 3 k-steps, 6 output blocks)
+                                      (2, 3, 201, 80), (1, 2, 64, 96), (2, 2, 15, 72), (1, 1, 700, 88)])
 def test_attention_flat(cuda, B, H, T, hd):
     from lmx import kernels as Kk
 
@@ -231,7 +233,8 @@ def _window_ref(x_q, x_k, x_v, Gh, Gw, ws, heads, hd, pad_k, pad_v, q_stride=1):
                                                     (1, 64, 64, 14, 2, 64, 1), (1, 16, 16, 8, 4, 56, 2), (1, 20, 20, 14, 2, 56, 2),
                                                     # 4 x 4 windows take the one-wave-per-window kernel: padded grids, Q-pool
                                                     # (4 queries), an item count that is not a multiple of 4
-                                                    (1, 12, 12, 4, 2, 56, 2), (2, 10, 10, 4, 5, 56, 1), (1, 8, 8, 4, 1, 32, 1)])
+                                                    (1, 12, 12, 4, 2, 56, 2), (2, 10, 10, 4, 5, 56, 1), (1, 8, 8, 4, 1, 32, 1),
+                                                    (1, 20, 20, 14, 2, 80, 1), (1, 12, 12, 4, 2, 80, 1)])
 def test_attention_window(cuda, n, Gh, Gw, ws, heads, hd, qs):
     from lmx import kernels as Kk
 

@@ -173,11 +173,12 @@ def test_mask_decoder_matches_oracle(cuda):
         assert (st[i, 3], st[i, 4], st[i, 5], st[i, 6]) == (int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max()))
 
 
-def test_attention_relpos_bias(cuda):
+@pytest.mark.parametrize("hd", [64, 80])  # 80: SAM ViT-H, the attention kernel's wide head-dim class
+def test_attention_relpos_bias(cuda, hd):
     """Decomposed relative-position bias (SAM v1): global 16x16 grid and 14x14 windows with zero-padded keys."""
     from lmx import kernels as K
 
-    heads, hd = 2, 64
+    heads = 2
     D = heads * hd
     for (n, G, ws) in [(2, 16, 0), (1, 20, 14)]:
         S = ws or G
@@ -218,13 +219,14 @@ def test_attention_relpos_bias(cuda):
         assert err < 6e-3, f"rel-pos attention G={G} ws={ws}: max err {err}"
 
 
-def test_sam_vit_encoder_matches_oracle(cuda):
+@pytest.mark.parametrize("hidden,heads", [(128, 2), (160, 2)])  # head dim 64 (vit_b / vit_l) and 80 (vit_h)
+def test_sam_vit_encoder_matches_oracle(cuda, hidden, heads):
     """SAM v1 ImageEncoderViT (reference code path for sam_vit_* checkpoints): small config, windowed + global layers."""
     from lmx import sam, synth, weights
     from oracle import preprocess as OP
     from oracle import sam_vit as OV
 
-    cfg = sam.SamVitConfig(hidden=128, layers=3, heads=2, mlp=256, global_idx=(1,), window=14, image=512)
+    cfg = sam.SamVitConfig(hidden=hidden, layers=3, heads=heads, mlp=256, global_idx=(1,), window=14, image=512)
     sd = weights.synth_state_dict(sam.vit_param_spec(cfg), seed=61)
     frames = np.stack([synth.synth_frame(15, i) for i in (2, 33)], 0)
     pv = torch.from_numpy(np.stack([OP.sam_pixel_values(f, cfg.image) for f in frames], 0))

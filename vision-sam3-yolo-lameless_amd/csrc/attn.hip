@@ -72,11 +72,20 @@ __device__ __forceinline__ half4_t lds_tr_read(const half_t* p) {
 // counted s_waitcnt vmcnt + one raw s_barrier per tile.  The register-staged path loads a tile at the top of an
 // iteration and stores it to LDS at the bottom of the SAME iteration: with 64 key tiles per query block (Hiera global
 // attention, T = 4096) every iteration then waits out an L2/HBM latency.
-template <int QB, bool ONES, bool REL, bool DMA>
+// HDW: head-dim class.  64: LDS rows of 64 halfs, 2 k-steps for S, 4 output blocks.  96 (SAM ViT-H, head dim 80): LDS rows of
+// 128 halfs (16 chunks, swizzle over row & 15), 3 k-steps, 6 output blocks — the layout and the MFMA bookkeeping are the
+// same, only wider.
+template <int QB, bool ONES, bool REL, bool DMA, int HDW>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, const Geo geo, const int nQT) {
   constexpr int NSL = DMA ? 3 : 2;
-  __shared__ __attribute__((aligned(16))) half_t Ks[NSL][64 * 64];
-  __shared__ __attribute__((aligned(16))) half_t Vs[NSL][64 * 64];  // row-major [key][d], same swizzle as K
+  constexpr int KS = HDW / 32;            // 32-wide k-steps of S = K . Q^T
+  constexpr int NDB = HDW / 16;           // 16-wide blocks of the output head dim
+  constexpr int RW = HDW <= 64 ? 64 : 128;  // halfs per LDS row
+  constexpr int CPR = RW / 8;             // 16-byte chunks per row; XOR swizzle over row & (CPR - 1)
+  constexpr int NPASS = 64 * CPR / 256;   // staging passes of 256 threads over a 64-key tile
+  static_assert(!(DMA && HDW != 64) && !(ONES && HDW != 64), "LDS-DMA ring and the ones column are built for 64-wide rows");
+  __shared__ __attribute__((aligned(16))) half_t Ks[NSL][64 * RW];
+  __shared__ __attribute__((aligned(16))) half_t Vs[NSL][64 * RW];  // row-major [key][d], same swizzle as K
   static_assert(!(DMA && REL), "the relative-position bias is read from global memory inside the loop: vmcnt would not count DMAs only");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,14 +115,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
 
   // ---- Q fragments (B operand): lane holds Q[q = fr][d = 32*ks + 8*fg + j]
   const int q_base = qt * (64 * QB) + wave * (16 * QB);
-  half8_t qf[QB][2];
+  half8_t qf[QB][KS];
   int64_t qrow[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int tq = q_base + qb * 16 + fr;
     qrow[qb] = (tq < p.Tq) ? query_row(geo, b, tq) : -1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int d = ks * 32 + fg * 8;
       const bool ok = qrow[qb] >= 0 && d < hd;
       const half8_t qv = *reinterpret_cast<const half8_t*>(Q + (ok ? qrow[qb] * p.ldq + (int64_t)h * hd + d : 0));
@@ -130,20 +139,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
                    : nullptr;
   }
 
-  f32x4 oacc[QB][4];
+  f32x4 oacc[QB][NDB];
   float m_run[QB], l_run[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     m_run[qb] = -INFINITY;
     l_run[qb] = 0.f;
 #pragma unroll
-    for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int db = 0; db < NDB; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   // ---- staging assignment: chunk sc of key kk = sk + 32*i
-  const int sc = tid & 7;
-  const int sk = tid >> 3;
-  half8_t kst[2], vst[2];
+  const int sc = tid & (CPR - 1);
+  const int sk = tid / CPR;  // 32 (or 16) keys per pass
+  constexpr int KPP = 256 / CPR;
+  half8_t kst[NPASS], vst[NPASS];
   // per-thread base pointers: everything that does not depend on the key index is hoisted out of the tile loop
   const int64_t hoff0 = (int64_t)h * hd + sc * 8;
   const half_t* Kb = K + hoff0 + (geo.mode == 0 ? (int64_t)b * p.Tk * p.ldk : 0);
@@ -152,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
   auto load_tile = [&](int t0) {
     if (geo.mode == 0) {  // flat geometry (wave-uniform branch): row = b*Tk + t, no padding keys
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int t = t0 + sk + 32 * i;
+      for (int i = 0; i < NPASS; ++i) {
+        const int t = t0 + sk + KPP * i;
         const bool in = d_ok && t < p.Tk;
         const int tt = in ? t : 0;
         const half8_t kv = *reinterpret_cast<const half8_t*>(Kb + (int64_t)tt * p.ldk);
@@ -165,8 +175,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
       return;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int t = t0 + sk + 32 * i;
+    for (int i = 0; i < NPASS; ++i) {
+      const int t = t0 + sk + KPP * i;
       const int d = sc * 8;
       // branch-free: every lane always loads 16 bytes from SOME valid address and the result is selected afterwards.
       // (Loads under divergent `if`s made hipcc wait for each one in turn: ~4 exposed HBM/L2 latencies per tile.)
@@ -185,9 +195,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kk = sk + 32 * i;
-      const int off = kk * 64 + ((sc ^ (kk & 7)) << 3);
+    for (int i = 0; i < NPASS; ++i) {
+      const int kk = sk + KPP * i;
+      const int off = kk * RW + ((sc ^ (kk & (CPR - 1))) << 3);
       *reinterpret_cast<half8_t*>(&Ks[buf][off]) = kst[i];
       *reinterpret_cast<half8_t*>(&Vs[buf][off]) = vst[i];
     }
@@ -263,11 +273,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) sacc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff = (((ks << 2) + fg) ^ (fr & 7)) << 3;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int coff = (((ks << 2) + fg) ^ (fr & (CPR - 1))) << 3;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[buf][(kb * 16 + fr) * 64 + coff]);
+        const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[buf][(kb * 16 + fr) * RW + coff]);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
           sacc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qb][ks], sacc[qb][kb], 0, 0, 0);
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
       if (!ONES) l_run[qb] = l_run[qb] * alpha + rs;
       if (grew) {
 #pragma unroll
-        for (int db = 0; db < 4; ++db) oacc[qb][db] *= alpha;
+        for (int db = 0; db < NDB; ++db) oacc[qb][db] *= alpha;
       }
     }
 
@@ -335,11 +345,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
+      for (int db = 0; db < NDB; ++db) {
         const int chunk = db * 2 + (p4 >> 1);
         const int r0 = ks * 32 + fg * 4 + q4, r1 = r0 + 16;
-        const half4_t lo = lds_tr_read(&Vs[buf][r0 * 64 + ((chunk ^ (r0 & 7)) << 3) + (p4 & 1) * 4]);
-        const half4_t hi = lds_tr_read(&Vs[buf][r1 * 64 + ((chunk ^ (r1 & 7)) << 3) + (p4 & 1) * 4]);
+        const half4_t lo = lds_tr_read(&Vs[buf][r0 * RW + ((chunk ^ (r0 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
+        const half4_t hi = lds_tr_read(&Vs[buf][r1 * RW + ((chunk ^ (r1 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
         half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if (DMA && ONES && db == 3) {  // row d = 63 of V^T (lanes fr == 15) is the ones row: the staged tile holds zeros there
           const half_t one = (half_t)1.0f;
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
     const float inv = 1.0f / l;
     if (qrow[qb] < 0) continue;
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
+    for (int db = 0; db < NDB; ++db) {
       const int d = db * 16 + fg * 4;
       if (d >= hd) continue;
       half4_t o;
@@ -501,9 +511,9 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(const lmx_attn_desc 
       continue;
     }
     const half_t* q = reinterpret_cast<const half_t*>(p.Q) + row * p.ldq + (int64_t)h * hd;
-    float qv[64];
+    float qv[96];
 #pragma unroll
-    for (int c = 0; c < 64; c += 8) {
+    for (int c = 0; c < 96; c += 8) {
       if (c < hd) {
         const half8_t v = *reinterpret_cast<const half8_t*>(q + c);
 #pragma unroll
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(const lmx_attn_desc 
       const float* r2 = rw + (int64_t)(tx - j + S - 1) * hd;
       float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-      for (int c = 0; c < 64; ++c) {
+      for (int c = 0; c < 96; ++c) {
         if (c < hd) {
           a1 = fmaf(qv[c], r1[c], a1);
           a2 = fmaf(qv[c], r2[c], a2);
@@ -539,7 +549,7 @@ extern "C" int lmx_k_relpos_tables(const lmx_attn_desc* dp, const float* rel_pos
                                    lmx_stream_t stream) {
   LMX_REQUIRE(dp && rel_pos_h && rel_pos_w && out, "lmx_k_relpos_tables: null pointer");
   const lmx_attn_desc& d = *dp;
-  LMX_REQUIRE(d.Q && d.B > 0 && d.H > 0 && d.Tq > 0 && d.hd % 8 == 0 && d.hd <= 64 && d.ldq % 8 == 0 && aligned16(d.Q),
+  LMX_REQUIRE(d.Q && d.B > 0 && d.H > 0 && d.Tq > 0 && d.hd % 8 == 0 && d.hd <= 96 && d.ldq % 8 == 0 && aligned16(d.Q),
               "lmx_k_relpos_tables: descriptor");
   LMX_REQUIRE(S > 0 && S * S == d.Tq, "lmx_k_relpos_tables: S=%d vs Tq=%d", S, d.Tq);
   Geo g{};
@@ -558,7 +568,7 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   const lmx_attn_desc& d = *dp;
   LMX_REQUIRE(d.Q && d.K && d.V && d.O, "lmx_k_attention: null Q/K/V/O");
   LMX_REQUIRE(d.B > 0 && d.H > 0 && d.Tq > 0 && d.Tk > 0, "lmx_k_attention: empty problem");
-  LMX_REQUIRE(d.hd % 8 == 0 && d.hd > 0 && d.hd <= 64, "lmx_k_attention: head dim %d (need multiple of 8, <=64)", d.hd);
+  LMX_REQUIRE(d.hd % 8 == 0 && d.hd > 0 && d.hd <= 96, "lmx_k_attention: head dim %d (need multiple of 8, <=96)", d.hd);
   LMX_REQUIRE(d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 4 == 0, "lmx_k_attention: strides");
   LMX_REQUIRE(aligned16(d.Q) && aligned16(d.K) && aligned16(d.V) && ((((uintptr_t)d.O) & 7) == 0),
               "lmx_k_attention: alignment");
@@ -569,13 +579,14 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-  if (d.Tq <= 16 && d.Tk <= 16 && !d.rel) {  // one wave per (batch | window, head)
+  if (d.Tq <= 16 && d.Tk <= 16 && !d.rel && d.hd <= 64) {  // one wave per (batch | window, head)
     const int64_t items = (int64_t)d.B * d.H;
     LMX_REQUIRE(items < (1ll << 31), "lmx_k_attention: grid too large");
     hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, d, g, (int)items);
     return lmx_launch_check("attn_small_kernel");
   }
-  const bool big = d.Tq > 64;
+  const bool wide = d.hd > 64;  // SAM ViT-H (head dim 80): 128-half LDS rows, one 16-query block per wave
+  const bool big = d.Tq > 64 && !wide;
   const int qtile = big ? 128 : 64;
   int nQT = (d.Tq + qtile - 1) / qtile;
   const int64_t nblk = (int64_t)d.B * d.H * nQT;
@@ -587,28 +598,32 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
     no_dma = getenv("LMX_ATTN_NO_DMA") ? 1 : 0;
     no_lazy = getenv("LMX_ATTN_NO_LAZY") ? 1 : 0;
   }
-  const bool dma = !no_dma && d.mode == 0 && !d.rel && big && d.Tk >= 256 && (int64_t)d.Tk * d.ldk * 2 < 0x7fff0000ll &&
+  const bool dma = !no_dma && !wide && d.mode == 0 && !d.rel && big && d.Tk >= 256 && (int64_t)d.Tk * d.ldk * 2 < 0x7fff0000ll &&
                    (int64_t)d.Tk * d.ldv * 2 < 0x7fff0000ll;
   if (no_lazy) nQT = -nQT;
   if (d.rel) {
     LMX_REQUIRE(d.rel_S > 0 && d.rel_S * d.rel_S == d.Tk && d.Tq == d.Tk, "lmx_k_attention: rel_S=%d does not match Tq=%d Tk=%d",
                 d.rel_S, d.Tq, d.Tk);
-    if (big)
-      hipLaunchKernelGGL((attn_kernel<2, false, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    if (wide)
+      hipLaunchKernelGGL((attn_kernel<1, false, true, false, 96>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    else if (big)
+      hipLaunchKernelGGL((attn_kernel<2, false, true, false, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
     else
-      hipLaunchKernelGGL((attn_kernel<1, false, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
-  } else if (dma && ones)
-    hipLaunchKernelGGL((attn_kernel<2, true, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+      hipLaunchKernelGGL((attn_kernel<1, false, true, false, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  } else if (wide)
+    hipLaunchKernelGGL((attn_kernel<1, false, false, false, 96>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  else if (dma && ones)
+    hipLaunchKernelGGL((attn_kernel<2, true, false, true, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else if (dma)
-    hipLaunchKernelGGL((attn_kernel<2, false, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    hipLaunchKernelGGL((attn_kernel<2, false, false, true, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else if (big && ones)
-    hipLaunchKernelGGL((attn_kernel<2, true, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    hipLaunchKernelGGL((attn_kernel<2, true, false, false, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else if (big)
-    hipLaunchKernelGGL((attn_kernel<2, false, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    hipLaunchKernelGGL((attn_kernel<2, false, false, false, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else if (ones)
-    hipLaunchKernelGGL((attn_kernel<1, true, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    hipLaunchKernelGGL((attn_kernel<1, true, false, false, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else
-    hipLaunchKernelGGL((attn_kernel<1, false, false, false>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+    hipLaunchKernelGGL((attn_kernel<1, false, false, false, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   return lmx_launch_check("attn_kernel");
 }
 

@@ -266,7 +266,7 @@ class HieraEncoder:
 
 # ======================================================================================================================
 # SAM v1 ImageEncoderViT — what `sam_model_registry["vit_b"|"vit_l"]` builds in services/sam3-pipeline/app/main.py:58-65
-# (SURVEY.md Appendix A.2).  vit_h has head dim 80 (> 64): not supported by the attention kernel yet.
+# (SURVEY.md Appendix A.2).  vit_h has head dim 80: the attention kernel's 96-wide head-dim class (csrc/attn.hip HDW).
 # ======================================================================================================================
 @dataclass
 class SamVitConfig:
@@ -292,6 +292,10 @@ def sam_vit_b():
 
 def sam_vit_l():
     return SamVitConfig(hidden=1024, layers=24, heads=16, mlp=4096, global_idx=(5, 11, 17, 23))
+
+
+def sam_vit_h():
+    return SamVitConfig(hidden=1280, layers=32, heads=16, mlp=5120, global_idx=(7, 15, 23, 31))
 
 
 def vit_param_spec(cfg):
