@@ -494,49 +494,67 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const lmx_attn_desc p, 
   }
 }
 
-// thread = one (b, h, t): q row in registers, 2S dot products against the relative-position rows (L1/L2 resident).
+// Decomposed relative-position tables on MFMA (TF:models/sam/modeling_sam.py get_decomposed_rel_pos / add_decomposed_rel_pos:
+// rel_h[b,h,(ty,tx),j] = q . Rh[ty - j + S - 1],  rel_w[b,h,(ty,tx),j] = q . Rw[tx - j + S - 1]).
+// For a fixed ty the S tokens of a grid row share their S rows of Rh, for a fixed tx the S tokens of a grid column share their
+// rows of Rw: each is a [S x hd] x [hd x S] product.  One wave = one (b, h, axis, line): A operand = the S relative-position
+// rows (f32 table -> f16 on the fly), B operand = the line's query rows (f16, straight from global memory), accumulator
+// lane (token, 4 consecutive j) -> one 8-byte store into the token's table row.  (The first version was one thread per
+// token looping over 2S x hd products: 1.6 ms per layer at S = 64, more than the layer's GEMMs.)
+template <int KS>
 __global__ __launch_bounds__(256) void relpos_tables_kernel(const lmx_attn_desc p, const Geo geo, const float* __restrict__ rh,
-                                                            const float* __restrict__ rw, int S, half_t* __restrict__ out) {
-  const int64_t total = (int64_t)p.B * p.H * p.Tq;
+                                                            const float* __restrict__ rw, int S, half_t* __restrict__ out,
+                                                            const int64_t items) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  if (item >= items) return;  // whole wave; no barrier in this kernel
+  // item -> (b, h, axis, line)
+  const int line = (int)(item % S);
+  const int axis = (int)((item / S) & 1);  // 0: rows share Rh (line = ty), 1: columns share Rw (line = tx)
+  const int64_t bh = item / (2 * S);
+  const int h = (int)(bh % p.H), b = (int)(bh / p.H);
   const int hd = p.hd;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int t = (int)(i % p.Tq);
-    const int64_t bh = i / p.Tq;
-    const int h = (int)(bh % p.H);
-    const int b = (int)(bh / p.H);
-    const int64_t row = query_row(geo, b, t);
-    half_t* o = out + i * (2 * S);
-    if (row < 0) {  // padded query of a window: its attention output is discarded
-      for (int j = 0; j < 2 * S; ++j) o[j] = (half_t)0.f;
-      continue;
+  const float* R = axis ? rw : rh;
+  const half_t* Q = reinterpret_cast<const half_t*>(p.Q);
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int nblk = (S + 15) / 16;
+  for (int mb = 0; mb < nblk; ++mb) {  // 16 tokens of the line
+    const int pos = mb * 16 + fr;      // position along the line
+    const int t = axis ? pos * S + line : line * S + pos;
+    const int64_t qrow = pos < S ? query_row(geo, b, t) : -1;
+    half8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d = ks * 32 + fg * 8;
+      const bool ok = qrow >= 0 && d < hd;
+      const half8_t qv = *reinterpret_cast<const half8_t*>(Q + (ok ? qrow * p.ldq + (int64_t)h * hd + d : 0));
+      qf[ks] = ok ? qv : zero8;
     }
-    const half_t* q = reinterpret_cast<const half_t*>(p.Q) + row * p.ldq + (int64_t)h * hd;
-    float qv[96];
+    half_t* orow = out + ((bh * p.Tq) + (pos < S ? t : 0)) * (2 * S) + axis * S;
+    for (int jb = 0; jb < nblk; ++jb) {  // 16 relative offsets
+      const int j = jb * 16 + fr;        // A-operand row of this lane
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 96; c += 8) {
-      if (c < hd) {
-        const half8_t v = *reinterpret_cast<const half8_t*>(q + c);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[c + e] = (float)v[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[c + e] = 0.f;
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d = ks * 32 + fg * 8;
+        const bool ok = j < S && d < hd;
+        const float* rp = R + (ok ? (int64_t)(line - j + S - 1) * hd + d : 0);
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + (ok ? 4 : 0));
+        const half8_t rf = {(half_t)r0[0], (half_t)r0[1], (half_t)r0[2], (half_t)r0[3],
+                            (half_t)r1[0], (half_t)r1[1], (half_t)r1[2], (half_t)r1[3]};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ok ? rf : zero8, qf[ks], acc, 0, 0, 0);
       }
-    }
-    const int ty = t / S, tx = t - ty * S;
-    for (int j = 0; j < S; ++j) {
-      const float* r1 = rh + (int64_t)(ty - j + S - 1) * hd;
-      const float* r2 = rw + (int64_t)(tx - j + S - 1) * hd;
-      float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-      for (int c = 0; c < 96; ++c) {
-        if (c < hd) {
-          a1 = fmaf(qv[c], r1[c], a1);
-          a2 = fmaf(qv[c], r2[c], a2);
+      // acc: lane (fr = token, fg) holds offsets j = 16*jb + 4*fg + i
+      const int j0 = jb * 16 + fg * 4;
+      if (pos < S && j0 < S) {
+        if (j0 + 3 < S && (S & 3) == 0) {
+          const half4_t o = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+          *reinterpret_cast<half4_t*>(orow + j0) = o;
+        } else {
+          for (int i = 0; i < 4 && j0 + i < S; ++i) orow[j0 + i] = (half_t)acc[i];
         }
       }
-      o[j] = (half_t)a1;
-      o[S + j] = (half_t)a2;
     }
   }
 }
@@ -555,11 +573,17 @@ extern "C" int lmx_k_relpos_tables(const lmx_attn_desc* dp, const float* rel_pos
   Geo g{};
   const int rc = build_geo(d, g);
   if (rc) return rc;
-  const int64_t total = (int64_t)d.B * d.H * d.Tq;
-  int64_t grid = (total + 255) / 256;
-  if (grid > 256 * 16) grid = 256 * 16;
-  hipLaunchKernelGGL(relpos_tables_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d, g,
-                     rel_pos_h, rel_pos_w, S, reinterpret_cast<half_t*>(out));
+  // padded queries of a window (row < 0) produce zeros: q is read as zero
+  const int64_t items = (int64_t)d.B * d.H * 2 * S;
+  const int64_t grid = (items + 3) / 4;
+  LMX_REQUIRE(grid < (1ll << 31) && aligned16(rel_pos_h) && aligned16(rel_pos_w), "lmx_k_relpos_tables: size / alignment");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d.hd <= 64)
+    hipLaunchKernelGGL((relpos_tables_kernel<2>), dim3((unsigned)grid), dim3(256), 0, st, d, g, rel_pos_h, rel_pos_w, S,
+                       reinterpret_cast<half_t*>(out), items);
+  else
+    hipLaunchKernelGGL((relpos_tables_kernel<3>), dim3((unsigned)grid), dim3(256), 0, st, d, g, rel_pos_h, rel_pos_w, S,
+                       reinterpret_cast<half_t*>(out), items);
   return lmx_launch_check("relpos_tables_kernel");
 }
 
