@@ -180,7 +180,7 @@ def test_attention_relpos_bias(cuda, hd):
 
     heads = 2
     D = heads * hd
-    for (n, G, ws) in [(2, 16, 0), (1, 20, 14)]:
+    for (n, G, ws) in [(2, 16, 0), (1, 20, 14), (1, 64, 0)]:  # 64: the S == 64 fast path of the bias
         S = ws or G
         rows = n * G * G
         qkv = _rand((rows, 3 * D), 70, 1.0).half()
@@ -216,7 +216,8 @@ def test_attention_relpos_bias(cuda, hd):
             K.attention(d[:, :D], d[:, D:2 * D], d[:, 2 * D:], out, n, heads, G * G, G * G, hd, hd ** -0.5,
                         rel_pos=(rh.to(cuda), rw.to(cuda)))
         err = float((out.float().cpu() - ref).abs().max())
-        assert err < 6e-3, f"rel-pos attention G={G} ws={ws}: max err {err}"
+        # f16 probabilities and f16 bias tables against an fp32 reference: the error grows with the number of keys
+        assert err < (1e-2 if G * G > 1024 else 6e-3), f"rel-pos attention G={G} ws={ws}: max err {err}"
 
 
 @pytest.mark.parametrize("hidden,heads", [(128, 2), (160, 2)])  # head dim 64 (vit_b / vit_l) and 80 (vit_h)

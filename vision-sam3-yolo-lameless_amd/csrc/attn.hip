@@ -289,16 +289,28 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       if (REL) {
+        if (p.rel_S == 64) {
+          // global attention of the 64 x 64 grid: a 64-key tile is exactly grid row `it`, so the row term is one value per
+          // query and tile and the column terms of a lane's four keys are one 8-byte load — no index arithmetic
+          const float by = (float)relq[qb][it];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+          for (int kb = 0; kb < 4; ++kb) {
+            const half4_t bx = *reinterpret_cast<const half4_t*>(relq[qb] + 64 + kb * 16 + fg * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int key = t0 + kb * 16 + fg * 4 + r;
-            key = key < p.Tk ? key : 0;
-            const int ky = key / p.rel_S, kx = key - ky * p.rel_S;
-            const float bias = (float)relq[qb][ky] + (float)relq[qb][p.rel_S + kx];
-            sacc[qb][kb][r] = fmaf(sacc[qb][kb][r], p.scale, bias);
+            for (int r = 0; r < 4; ++r) sacc[qb][kb][r] = fmaf(sacc[qb][kb][r], p.scale, by + (float)bx[r]);
           }
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int key = t0 + kb * 16 + fg * 4 + r;
+              key = key < p.Tk ? key : 0;
+              const int ky = key / p.rel_S, kx = key - ky * p.rel_S;
+              const float bias = (float)relq[qb][ky] + (float)relq[qb][p.rel_S + kx];
+              sacc[qb][kb][r] = fmaf(sacc[qb][kb][r], p.scale, bias);
+            }
+        }
       }
       if (MASK) {  // only the last tile can hold keys >= Tk
 #pragma unroll
