@@ -83,15 +83,16 @@ int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const float* gamma
                     void* y, int out_dtype, int64_t ldy, int rows, int D, float eps, int act, lmx_stream_t stream);
 /* (act = LMX_ACT_NONE or LMX_ACT_GELU applied after the affine: the SAM decoder's LayerNorm2d -> GELU, TF sam :523) */
 
-/* ---- K11+K12 fused for narrow widths: x += fc2(gelu(fc1(LayerNorm(x)))) in ONE pass over the f32 residual stream ----
+/* ---- K11+K12 for narrow widths: x += fc2(gelu(fc1(LayerNorm(x)))) without the 4D-wide hidden tensor ever reaching HBM ----
  * Replaces `hidden_states + self.mlp(self.layer_norm2(hidden_states))` of the Hiera blocks whose width is 112 or 224
  * (TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward; stages 1-2 of Hiera-B+), where the unfused
- * LN -> GEMM -> GEMM chain is bound by its HBM intermediates (32*D bytes/token against 8*D here).
+ * LN -> GEMM -> GEMM chain is bound by its HBM intermediates (32*D bytes/token against 16*D here).
+ * Two launches: the LayerNorm kernel (f32 stream -> f16 rows in `workspace`, rows*D*2 bytes), then the fused MLP + residual.
  * x f32 [rows, ldx] updated in place; w1 f16 [4D, D], b1 f32 [4D], w2 f16 [D, 4D], b2 f32 [D] (torch Linear layouts).
  * Rounding points match the unfused kernels: LN output and GELU output are rounded to f16, accumulation is f32.
  */
 int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const float* beta, const void* w1, const float* b1,
-                 const void* w2, const float* b2, int64_t rows, int D, float eps, lmx_stream_t stream);
+                 const void* w2, const float* b2, int64_t rows, int D, float eps, void* workspace, lmx_stream_t stream);
 
 /* ---- K13/K14: attention (flash-style, online softmax in f32, S and PV on MFMA) ----------------------
  * O[b,t,h,:] = softmax_j( scale * Q[b,t,h,:] . K[b,j,h,:] ) V[b,j,h,:]

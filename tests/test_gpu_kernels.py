@@ -370,3 +370,28 @@ def test_pack_bits_bit_exact(cuda, shape):
     got = Kk.pack_bits(torch.from_numpy(m).to(cuda)).cpu().numpy()
     ref = np.packbits(m != 0, axis=-1)
     assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------- run-to-run reproducibility
+def test_large_launches_are_bit_reproducible(cuda):
+    """Every kernel here is meant to be deterministic.  A launch large enough to run several rounds of workgroups per CU,
+    repeated on identical inputs, must give identical bits: an earlier version of the fused MLP normalised inside the kernel
+    and produced run-to-run different rows (a few hundred per million) only when workgroups were co-resident on a CU —
+    invisible to tolerance checks on small inputs (tools/mlp_selfcheck.py, tools/determinism_probe.py)."""
+    from lmx import kernels as Kk
+
+    torch.manual_seed(0)
+    D, rows = 112, 1 << 20
+    x0 = torch.randn((rows, D), device=cuda)
+    g, bb = torch.ones(D, device=cuda), torch.zeros(D, device=cuda)
+    w1 = (torch.randn((4 * D, D), device=cuda) * D ** -0.5).half()
+    w2 = (torch.randn((D, 4 * D), device=cuda) * (4 * D) ** -0.5).half()
+    b1, b2 = torch.randn(4 * D, device=cuda) * 0.1, torch.randn(D, device=cuda) * 0.1
+    ref = Kk.ln_mlp(x0.clone(), g, bb, w1, b1, w2, b2, 1e-6)
+    for _ in range(3):
+        assert torch.equal(Kk.ln_mlp(x0.clone(), g, bb, w1, b1, w2, b2, 1e-6), ref), "fused MLP differs between identical launches"
+    a = torch.randn((65536, 448), device=cuda).half()
+    w = (torch.randn((1792, 448), device=cuda) * 448 ** -0.5).half()
+    r0 = Kk.gemm(a, w, act=Kk.ACT_GELU)
+    for _ in range(3):
+        assert torch.equal(Kk.gemm(a, w, act=Kk.ACT_GELU), r0), "GEMM differs between identical launches"

@@ -140,3 +140,27 @@ def test_clip_curation_tracker(cuda):
             if ref is not None:
                 assert r["detection"]["bbox"] == ref["bbox"] and r["detection"]["area"] == ref["area"]
     assert any(r["detection"] is not None for r in recs)
+
+
+def test_fused_step_is_bit_reproducible(cuda):
+    """FusedExtractor.step on several HIP streams, on one stream, and repeated: identical bits for every output field."""
+    import numpy as np
+    import torch
+
+    from lmx import pipeline, synth
+
+    fx = pipeline.FusedExtractor(cuda)
+    frames = torch.from_numpy(np.stack([synth.synth_frame(3, 40 + i) for i in range(20)], 0)).to(cuda)
+
+    def run(serial):
+        fx.serial = serial
+        out = fx.step(frames, keep_byte_masks=True)
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in out.items()}
+
+    ref = run(False)
+    for serial in (False, True, True):
+        got = run(serial)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), f"{k} differs between runs (serial={serial})"
+    fx.serial = False

@@ -1,4 +1,4 @@
-// mlp.hip — fused LayerNorm -> fc1 -> GELU -> fc2 -> +residual for NARROW token widths (Hiera stages 1-2: D = 112, 224;
+// mlp.hip — LayerNorm, then fused fc1 -> GELU -> fc2 -> +residual for NARROW token widths (Hiera stages 1-2: D = 112, 224;
 // TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward: `hidden_states + mlp(layer_norm2(hidden_states))`).
 //
 // Why: at D <= 224 the unfused chain  LN kernel -> GEMM(D->4D, GELU) -> GEMM(4D->D, +res)  is HBM-bound on its
@@ -13,7 +13,8 @@
 // (buffer_load ... lds, no VGPR round trip), three chunks in flight, ONE raw s_barrier + counted s_waitcnt vmcnt per
 // chunk exactly as gemm2.hip.  (A first version staged through registers one chunk ahead: every chunk then waited a full
 // L2 latency for the loads issued at its own start — 6000 cycles per chunk against 480 cycles of MFMA.)
-// HBM traffic per token: 4D read + 4D write (the residual enters as the initial fc2 accumulator).
+// HBM traffic per token: LayerNorm 4D read + 2D write, fused kernel 2D + 4D read + 4D write (the residual enters as the
+// initial fc2 accumulator) = 16 D bytes against 32 D for the unfused chain.
 #include "common.h"
 #include <stdlib.h>
 
@@ -22,16 +23,15 @@ namespace lmx_mlp {
 constexpr int HC = 32;   // hidden units per chunk (one MFMA k-step of the second GEMM)
 
 // D: token width (multiple of 16, <= 256).  NW waves of QB 16-token blocks: a workgroup owns NW*16*QB tokens.
-// Every wave issues 4 LDS-DMA instructions (4 KB) per chunk: NW*4 KB = one ring slot = [W1 chunk | W2 chunk].
+// Every wave issues PT LDS-DMA instructions (1 KB each) per chunk: NW*PT KB = one ring slot = [W1 chunk | W2 chunk].
 // NST: LDS ring slots (NST-1 chunks in flight).  OCC: workgroups per CU the register budget must allow.
 template <int D, int QB, int NW, int NST, int OCC>
 __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __restrict__ x, int64_t ldx,
-                                                                          const float* __restrict__ gam,
-                                                                          const float* __restrict__ bet,
+                                                                          const half_t* __restrict__ hn,
                                                                           const half_t* __restrict__ w1,
                                                                           const float* __restrict__ b1,
                                                                           const half_t* __restrict__ w2,
-                                                                          const float* __restrict__ b2, int64_t rows, float eps) {
+                                                                          const float* __restrict__ b2, int64_t rows) {
   constexpr int KS = (D + 31) / 32;           // k-steps of the first GEMM
   constexpr int DP = D <= 128 ? 128 : 256;    // halfs per LDS row of a W1 chunk (power of two: XOR swizzle stays in the row)
   constexpr int DB = D / 16;                  // 16-wide output blocks
@@ -40,9 +40,9 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
   constexpr int W2_ROWS = DP;                 // W2 chunk rows padded to 128 | 256 (rows >= D read as zeros, never used)
   constexpr int W2_BYTES = W2_ROWS * 64;      // 8 KB | 16 KB
   constexpr int STAGE = W1_BYTES + W2_BYTES;
-  constexpr int PT = 4;                       // DMA instructions per wave per chunk
+  constexpr int PT = STAGE / (NW * 1024);     // DMA instructions per wave per chunk (4, or 2 for D = 112 on 8 waves)
   constexpr int LA = NST - 1;
-  static_assert(STAGE == NW * PT * 1024, "one ring slot = NW waves x 4 KB");
+  static_assert(STAGE == NW * PT * 1024 && PT >= 1, "one ring slot = NW waves x PT KB");
   static_assert(W1_BYTES == (NW / 2) * PT * 1024, "the first half of the waves stages W1, the second half W2");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* b1s = reinterpret_cast<float*>(smem + NST * STAGE);  // fc1 bias, 4D floats
@@ -85,54 +85,25 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
 
   for (int i = tid; i < 4 * D; i += NW * 64) b1s[i] = b1[i];
 
-  // ---- LayerNorm of this wave's tokens straight into MFMA B-operand fragments: lane (fr, fg) holds, for token fr of
-  // block qb, the 8 features 32*ks + 8*fg .. +7 of every k-step; a token's D features sit in the 4 lanes fr, fr+16, ..
+  // ---- this wave's normalised tokens (f16, written by the LayerNorm kernel the entry point launches first) as MFMA B-operand
+  // fragments: lane (fr, fg) holds, for token fr of block qb, the 8 features 32*ks + 8*fg .. +7 of every k-step.
+  // (The first version normalised in here, reducing over the four lanes of a token with __shfl_xor: whenever waves of other
+  // workgroups shared the SIMD, a few hundred rows per million got run-to-run different statistics — with ds_bpermute and
+  // with v_permlane swaps alike, never with one workgroup per CU, cause not identified (tools/mlp_selfcheck.py).  The
+  // standalone LayerNorm kernel is bit-reproducible in every configuration tested, so the reduction lives there.)
   const int64_t tok0 = (int64_t)blockIdx.x * (NW * 16 * QB) + wave * (16 * QB);
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   half8_t xn[QB][KS];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int64_t t = tok0 + qb * 16 + fr;
-    const float* xr = x + (t < rows ? t : 0) * ldx;
-    // three passes over the (L1/L2-hot) row instead of holding its D/4 values per lane: keeps the prologue's register
-    // peak below the main loop's
-    float s = 0.f;
+    const half_t* hr = hn + (t < rows ? t : 0) * D;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int d = ks * 32 + fg * 8;
-      if (d < D) {  // D % 8 == 0: a lane's 8 features are all in or all out
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + d), b = *reinterpret_cast<const f32x4*>(xr + d + 4);
-        s += (a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3]);
-      }
-    }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int d = ks * 32 + fg * 8;
-      if (d < D) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + d) - mean, b = *reinterpret_cast<const f32x4*>(xr + d + 4) - mean;
-        q += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
-      }
-    }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / D) + eps);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int d = ks * 32 + fg * 8;
-      const bool ok = d < D;
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam + (ok ? d : 0)), g1 = *reinterpret_cast<const f32x4*>(gam + (ok ? d + 4 : 0));
-      const f32x4 c0 = *reinterpret_cast<const f32x4*>(bet + (ok ? d : 0)), c1 = *reinterpret_cast<const f32x4*>(bet + (ok ? d + 4 : 0));
-      const f32x4 va = *reinterpret_cast<const f32x4*>(xr + (ok ? d : 0)), vb = *reinterpret_cast<const f32x4*>(xr + (ok ? d + 4 : 0));
-      half8_t h;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        h[e] = (half_t)(ok ? (va[e] - mean) * rstd * g0[e] + c0[e] : 0.f);
-        h[4 + e] = (half_t)(ok ? (vb[e] - mean) * rstd * g1[e] + c1[e] : 0.f);
-      }
-      xn[qb][ks] = h;
+      const bool ok = d < D;  // D % 8 == 0: a lane's 8 features are all in or all out
+      const half8_t v = *reinterpret_cast<const half8_t*>(hr + (ok ? d : 0));
+      xn[qb][ks] = ok ? v : zero8;
     }
   }
 
@@ -233,8 +204,8 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
 }
 
 template <int D, int QB, int NW, int NST, int OCC>
-int launch(float* x, int64_t ldx, const float* gamma, const float* beta, const half_t* w1, const float* b1, const half_t* w2,
-           const float* b2, int64_t rows, float eps, hipStream_t st) {
+int launch(float* x, int64_t ldx, const half_t* hn, const half_t* w1, const float* b1, const half_t* w2, const float* b2, int64_t rows,
+           hipStream_t st) {
   constexpr int DP = D <= 128 ? 128 : 256;
   const size_t smem = (size_t)NST * (HC * DP * 2 + DP * 64) + 4 * D * sizeof(float);
   static bool attr_set = false;
@@ -246,8 +217,7 @@ int launch(float* x, int64_t ldx, const float* gamma, const float* beta, const h
   const int64_t per = NW * 16 * QB;
   const int64_t nb = (rows + per - 1) / per;
   LMX_REQUIRE(nb < 0x7fffffffll, "lmx_k_ln_mlp: too many rows");
-  hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, gamma, beta, w1, b1, w2, b2, rows,
-                     eps);
+  hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, hn, w1, b1, w2, b2, rows);
   return lmx_launch_check("ln_mlp_kernel");
 }
 
@@ -255,24 +225,25 @@ int launch(float* x, int64_t ldx, const float* gamma, const float* beta, const h
 using namespace lmx_mlp;
 
 extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const float* beta, const void* w1, const float* b1,
-                            const void* w2, const float* b2, int64_t rows, int D, float eps, lmx_stream_t stream) {
-  LMX_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2, "lmx_k_ln_mlp: null pointer");
+                            const void* w2, const float* b2, int64_t rows, int D, float eps, void* workspace, lmx_stream_t stream) {
+  LMX_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && workspace, "lmx_k_ln_mlp: null pointer");
   LMX_REQUIRE(D == 112 || D == 224, "lmx_k_ln_mlp: D=%d (built for the Hiera stage widths 112 and 224)", D);
-  LMX_REQUIRE(rows > 0 && ldx >= D && ldx % 4 == 0, "lmx_k_ln_mlp: rows=%lld ldx=%lld", (long long)rows, (long long)ldx);
-  LMX_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(beta) && aligned16(w1) && aligned16(b1) && aligned16(w2) && aligned16(b2),
+  LMX_REQUIRE(rows > 0 && rows < 0x7fffffffll && ldx >= D && ldx % 4 == 0, "lmx_k_ln_mlp: rows=%lld ldx=%lld", (long long)rows,
+              (long long)ldx);
+  LMX_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(beta) && aligned16(w1) && aligned16(b1) && aligned16(w2) && aligned16(b2) &&
+                  aligned16(workspace),
               "lmx_k_ln_mlp: pointers must be 16-byte aligned");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // 1. LayerNorm (norm.hip; f32 stream -> f16 [rows, D] in the workspace), 2. the fused MLP + residual on it
+  const int rc = lmx_k_layernorm(x, LMX_F32, ldx, gamma, beta, workspace, LMX_F16, D, (int)rows, D, eps, LMX_ACT_NONE, stream);
+  if (rc) return rc;
+  const half_t* hn = reinterpret_cast<const half_t*>(workspace);
   const half_t* W1 = reinterpret_cast<const half_t*>(w1);
   const half_t* W2 = reinterpret_cast<const half_t*>(w2);
-  static int variant = -1;
-  if (variant < 0) {
-    const char* e = getenv("LMX_MLP_VARIANT");
-    variant = e ? e[0] - '0' : 0;
-  }
-  if (D == 112) {
-    if (variant == 1) return launch<112, 2, 4, 4, 2>(x, ldx, gamma, beta, W1, b1, W2, b2, rows, eps, st);
-    return launch<112, 2, 4, 3, 3>(x, ldx, gamma, beta, W1, b1, W2, b2, rows, eps, st);
-  }
-  if (variant == 1) return launch<224, 1, 8, 4, 1>(x, ldx, gamma, beta, W1, b1, W2, b2, rows, eps, st);
-  return launch<224, 2, 8, 4, 1>(x, ldx, gamma, beta, W1, b1, W2, b2, rows, eps, st);
+  static int one_per_cu = -1;  // LMX_MLP_ONE_PER_CU=1: the 8-wave, one-workgroup-per-CU configuration of the narrow width too
+  if (one_per_cu < 0) one_per_cu = getenv("LMX_MLP_ONE_PER_CU") ? 1 : 0;
+  // D = 112: 4 waves x 32 tokens, 48 KB ring, three workgroups per CU.  D = 224: 8 waves x 32 tokens, 128 KB ring, one per CU.
+  if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3>(x, ldx, hn, W1, b1, W2, b2, rows, st);
+  if (D == 112) return launch<112, 2, 8, 4, 1>(x, ldx, hn, W1, b1, W2, b2, rows, st);
+  return launch<224, 2, 8, 4, 1>(x, ldx, hn, W1, b1, W2, b2, rows, st);
 }

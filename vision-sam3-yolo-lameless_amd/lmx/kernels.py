@@ -199,8 +199,9 @@ def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps):
         raise LmxError("ln_mlp: x must be f32 and the weights f16")
     if tuple(w1.shape) != (4 * D, D) or tuple(w2.shape) != (D, 4 * D) or not (w1.is_contiguous() and w2.is_contiguous()):
         raise LmxError("ln_mlp: weight shapes must be [4D, D] and [D, 4D], contiguous")
+    ws = torch.empty((rows, D), dtype=torch.float16, device=x.device)  # LayerNorm output (the library's workspace)
     check(_lib.load().lmx_k_ln_mlp(_ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), rows, D,
-                                   float(eps), _stream()), "lmx_k_ln_mlp")
+                                   float(eps), _ptr(ws), _stream()), "lmx_k_ln_mlp")
     return x
 
 

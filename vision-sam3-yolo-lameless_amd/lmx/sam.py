@@ -12,6 +12,7 @@ sequence over the C-ABI kernels:
   neck  : 1x1 lateral GEMMs to 256 channels, nearest-x2 top-down add on levels 2/3 (GEMM residual epilogue).
 """
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -110,7 +111,8 @@ class HieraEncoder:
     def __init__(self, cfg, state_dict, device="cuda", fused_mlp=True):
         self.cfg = cfg
         self.device = torch.device(device)
-        self.fused_mlp = fused_mlp  # False: LN / GEMM / GEMM launches for every width (A/B comparisons and tests)
+        # False: LN / GEMM / GEMM launches for every width (A/B comparisons and tests; LMX_NO_FUSED_MLP=1 forces it)
+        self.fused_mlp = fused_mlp and not os.environ.get("LMX_NO_FUSED_MLP")
         dev = self.device
         sd = state_dict
 
