@@ -18,6 +18,8 @@ class FusedExtractor:
 
         self.device = torch.device(device)
         self.serial = bool(os.environ.get("LMX_SERIAL"))  # True: every launch on the caller's stream
+        self.max_streams = int(os.environ.get("LMX_MAX_STREAMS", "4"))  # HIP streams one step may keep in flight (>= 3)
+        self.stream_layout = os.environ.get("LMX_STREAM_LAYOUT", "lanes")
         ycfg = yolo.YoloConfig(yolo_scale)
         bn = yolo_bn or os.path.join(GOLDEN, f"yolov8{yolo_scale}_bn_w{weight_seeds[0]}.npz")
         self.yolo = yolo.YoloDetector(ycfg, yolo.synthetic_state_dict(ycfg, weight_seeds[0], bn if os.path.exists(bn) else None),
@@ -51,12 +53,22 @@ class FusedExtractor:
         if self.serial:
             det_stream, emb_stream, sam_streams = main, main, [main] * len(chunks)
         else:
-            pool = self._streams(2 + len(chunks))
-            det_stream, emb_stream, sam_streams = pool[0], pool[1], pool[2:]
+            # "lanes": YOLO and DINO on a stream each, the SAM chunks dealt over the remaining max_streams - 2 streams (two
+            # chunks in flight at the default of 4); "rr": everything dealt round-robin over max_streams streams
+            pool = self._streams(max(3, min(2 + len(chunks), self.max_streams)))
+            k = len(pool)
+            if self.stream_layout == "rr":
+                det_stream, emb_stream = pool[0], pool[1]
+                sam_streams = [pool[(2 + j) % k] for j in range(len(chunks))]
+            else:
+                det_stream, emb_stream = pool[0], pool[1]
+                sam_streams = [pool[2 + j % (k - 2)] for j in range(len(chunks))]
             for st in pool:
                 st.wait_stream(main)  # frames were produced on the caller's stream
         with torch.cuda.stream(det_stream):
             boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf)
+            det_done = torch.cuda.Event()
+            det_done.record(det_stream)
         with torch.cuda.stream(emb_stream):
             emb = self.dino.embed_frames(frames)
         masks, stats, ious = [], [], []
@@ -64,7 +76,7 @@ class FusedExtractor:
             with torch.cuda.stream(st):
                 enc = self.sam.encode(frames[i:i + sam_chunk])
                 e2 = enc["fpn"][2]
-                st.wait_stream(det_stream)  # the decoder needs the boxes
+                st.wait_event(det_done)  # the decoder needs the boxes
                 # the service prompts SAM with the first (highest-confidence) detection of the frame (sam3 main.py:199-206);
                 # frames without a detection are decoded against an all-zero box and flagged by counts == 0
                 d = self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes[i:i + sam_chunk, 0, :], (h, w), rhw)
