@@ -158,8 +158,12 @@ __device__ __forceinline__ float sample_mid(const float* __restrict__ lg, int L,
 }
 
 // pass 1: the T x T bilinear upsample of the L x L logits, only the [nh][nw] crop that pass 2 reads
+// DBG 0 is the product.  LMX_DBG_MASK (development only, tools/stream_race_probe.py): 1 = pass 2 reads the intermediate
+// with plain loads (the defect described at ld_mid); 2 = plain loads, and pass 1 counts its finished workgroups in
+// stats[7] while pass 2 counts in stats[15] the workgroups that started before that count was complete (never seen)
+template <int DBG>
 __global__ __launch_bounds__(256) void mask_mid_kernel(const float* __restrict__ logits, float* __restrict__ mid, int n, int L,
-                                                       int T, int nh, int nw) {
+                                                       int T, int nh, int nw, unsigned long long* dbg) {
   const float sLT = (float)L / (float)T;
   const int64_t total = (int64_t)n * nh * nw;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -169,13 +173,35 @@ __global__ __launch_bounds__(256) void mask_mid_kernel(const float* __restrict__
     const int b = (int)(r / nh);
     mid[i] = sample_mid(logits + (int64_t)b * L * L, L, T, sLT, Y, X);
   }
+  if (DBG == 2) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&dbg[7], 1ull);
+  }
+}
+
+// Pass 2 reads what pass 1 (the previous launch on the same stream) wrote.  With three or more SAM passes in flight on
+// separate streams, plain loads here returned, for a few of 9.4 M values per launch, what the address held BEFORE pass 1
+// — although every pass-1 workgroup had finished before the first pass-2 workgroup started (DBG 2 counts that).  The
+// kernel-boundary cache maintenance did not make those lines visible across XCDs; system-scope loads (sc0 sc1: served
+// coherently, not from this XCD's possibly stale L2 line) do, at +4 % on this kernel.  DESIGN.md section 6.
+template <int DBG>
+__device__ __forceinline__ float ld_mid(const float* p) {
+  if (DBG == 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return *p;
 }
 
 // pass 2: bilinear [nh][nw] -> [h][w], > 0, statistics.  A thread produces 4 consecutive pixels of one row (row
 // interpolation weights computed once, one 4-byte store instead of four byte stores).
+template <int DBG>
 __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict__ mid, int n, int nh, int nw, int h, int w,
-                                                        uint8_t* __restrict__ mask, unsigned long long* __restrict__ stats) {
+                                                        uint8_t* __restrict__ mask, unsigned long long* __restrict__ stats,
+                                                        unsigned expect) {
   const int b = blockIdx.y;
+  if (DBG == 2 && threadIdx.x == 0) {
+    const unsigned long long c = __hip_atomic_load(&stats[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c < expect) atomicAdd(&stats[15], 1ull);
+  }
   const float* md = mid + (int64_t)b * nh * nw;
   const float sy = (float)nh / (float)h, sx = (float)nw / (float)w;
   unsigned long long area = 0, sumx = 0, sumy = 0;
@@ -198,8 +224,8 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
       int X0, X1;
       float lx;
       bil_idx(sx, x, nw, X0, X1, lx);
-      const float t0 = (1.f - lx) * r0[X0] + lx * r0[X1];
-      const float t1 = (1.f - lx) * r1[X0] + lx * r1[X1];
+      const float t0 = (1.f - lx) * ld_mid<DBG>(r0 + X0) + lx * ld_mid<DBG>(r0 + X1);
+      const float t1 = (1.f - lx) * ld_mid<DBG>(r1 + X0) + lx * ld_mid<DBG>(r1 + X1);
       const float v = (1.f - ly) * t0 + ly * t1;
       if (v > 0.0f) {
         packed |= 1u << (8 * e);
@@ -404,9 +430,19 @@ extern "C" int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh,
   hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, st, reinterpret_cast<long long*>(stats), n);
   int gx = (int)(((int64_t)h * ((w + 3) / 4) + 255) / 256);
   if (gx > 96) gx = 96;  // 96 blocks x n frames: >= 3000 blocks at the bench batch, and only 96 x 7 atomics per frame
-  hipLaunchKernelGGL(mask_mid_kernel, dim3(grid_for((int64_t)n * nh * nw)), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw);
-  hipLaunchKernelGGL(mask_post_kernel, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask,
-                     reinterpret_cast<unsigned long long*>(stats));
+  static const int dbg = getenv("LMX_DBG_MASK") ? atoi(getenv("LMX_DBG_MASK")) : 0;
+  const unsigned gmid = grid_for((int64_t)n * nh * nw);
+  unsigned long long* su = reinterpret_cast<unsigned long long*>(stats);
+  if (dbg == 2 && n >= 2) {
+    hipLaunchKernelGGL(mask_mid_kernel<2>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+    hipLaunchKernelGGL(mask_post_kernel<2>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+  } else if (dbg == 1) {
+    hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+    hipLaunchKernelGGL(mask_post_kernel<1>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+  } else {
+    hipLaunchKernelGGL(mask_mid_kernel<0>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+    hipLaunchKernelGGL(mask_post_kernel<0>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+  }
   return lmx_launch_check("mask_post_kernel");
 }
 
