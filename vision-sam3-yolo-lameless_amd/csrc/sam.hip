@@ -160,7 +160,8 @@ __device__ __forceinline__ float sample_mid(const float* __restrict__ lg, int L,
 // pass 1: the T x T bilinear upsample of the L x L logits, only the [nh][nw] crop that pass 2 reads
 // DBG 0 is the product.  LMX_DBG_MASK (development only, tools/stream_race_probe.py): 1 = pass 2 reads the intermediate
 // with plain loads (the defect described at ld_mid); 2 = plain loads, and pass 1 counts its finished workgroups in
-// stats[7] while pass 2 counts in stats[15] the workgroups that started before that count was complete (never seen)
+// stats[7] while pass 2 counts in stats[15] the workgroups that started before that count was complete (never seen);
+// 3 = plain loads, system-scope release fence at the end of pass 1; 4 = plain loads, system-scope acquire fence at the start of pass 2; 5 = both fences
 template <int DBG>
 __global__ __launch_bounds__(256) void mask_mid_kernel(const float* __restrict__ logits, float* __restrict__ mid, int n, int L,
                                                        int T, int nh, int nw, unsigned long long* dbg) {
@@ -178,13 +179,14 @@ __global__ __launch_bounds__(256) void mask_mid_kernel(const float* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&dbg[7], 1ull);
   }
+  if (DBG == 3 || DBG == 5) __atomic_thread_fence(__ATOMIC_RELEASE);  // system-scope release (L2 write-back) by every wave of pass 1
 }
 
 // Pass 2 reads what pass 1 (the previous launch on the same stream) wrote.  With three or more SAM passes in flight on
-// separate streams, plain loads here returned, for a few of 9.4 M values per launch, what the address held BEFORE pass 1
-// — although every pass-1 workgroup had finished before the first pass-2 workgroup started (DBG 2 counts that).  The
-// kernel-boundary cache maintenance did not make those lines visible across XCDs; system-scope loads (sc0 sc1: served
-// coherently, not from this XCD's possibly stale L2 line) do, at +4 % on this kernel.  DESIGN.md section 6.
+// separate streams, plain loads here returned, for a few of 9.4 M values per launch, something other than what pass 1
+// wrote — although every pass-1 workgroup had finished before the first pass-2 workgroup started (DBG 2 counts that),
+// and with or without system-scope release/acquire fences around the boundary (DBG 3/4/5).  System-scope loads
+// (sc0 sc1) never did, at +4 % on this kernel.  Cause not identified; DESIGN.md section 6 has the measurements.
 template <int DBG>
 __device__ __forceinline__ float ld_mid(const float* p) {
   if (DBG == 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
                                                         uint8_t* __restrict__ mask, unsigned long long* __restrict__ stats,
                                                         unsigned expect) {
   const int b = blockIdx.y;
+  if (DBG == 4 || DBG == 5) __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system-scope acquire (cache invalidate) by every wave of pass 2
   if (DBG == 2 && threadIdx.x == 0) {
     const unsigned long long c = __hip_atomic_load(&stats[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c < expect) atomicAdd(&stats[15], 1ull);
@@ -436,6 +439,15 @@ extern "C" int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh,
   if (dbg == 2 && n >= 2) {
     hipLaunchKernelGGL(mask_mid_kernel<2>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
     hipLaunchKernelGGL(mask_post_kernel<2>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+  } else if (dbg == 3) {  // plain loads + release at the end of pass 1
+    hipLaunchKernelGGL(mask_mid_kernel<3>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+    hipLaunchKernelGGL(mask_post_kernel<3>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+  } else if (dbg == 4) {  // plain loads + acquire at the start of pass 2
+    hipLaunchKernelGGL(mask_mid_kernel<4>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+    hipLaunchKernelGGL(mask_post_kernel<4>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+  } else if (dbg == 5) {  // plain loads + both fences
+    hipLaunchKernelGGL(mask_mid_kernel<5>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+    hipLaunchKernelGGL(mask_post_kernel<5>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
   } else if (dbg == 1) {
     hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
     hipLaunchKernelGGL(mask_post_kernel<1>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
