@@ -183,3 +183,25 @@ def test_clip_curation_best_detection_rule():
     cls2 = np.asarray([3, 3, 3, 3], np.int32)
     assert best_detection(boxes[:2], scores, cls2, 2, 1080, 1920) is None  # small non-cow boxes are ignored
     assert best_detection(boxes, scores, cls, 0, 1080, 1920) is None
+
+
+def test_stream_plan_layouts():
+    """FusedExtractor's stream assignment: at most two SAM passes in flight by default."""
+    from lmx.pipeline import stream_plan
+
+    assert stream_plan(4) == (4, 0, 1, [2, 3, 2, 3])               # bench batch: 64 frames, passes of 16
+    assert stream_plan(2) == (4, 0, 1, [2, 3])
+    assert stream_plan(1) == (3, 0, 1, [2])
+    assert stream_plan(4, 6) == (6, 0, 1, [2, 3, 4, 5])
+    assert stream_plan(4, 1) == (3, 0, 1, [2, 2, 2, 2])            # never fewer than YOLO, DINO and one SAM stream
+    assert stream_plan(4, 3, "rr") == (3, 0, 1, [2, 0, 1, 2])
+    for n in range(1, 9):
+        for cap in range(1, 8):
+            k, d, e, sam = stream_plan(n, cap)
+            assert len(sam) == n and d != e and all(2 <= s < k for s in sam) and len(set(sam)) <= max(1, min(cap, 2 + n) - 2)
+    try:
+        stream_plan(2, 4, "spiral")
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("an unknown layout must be refused")

@@ -11,6 +11,18 @@ from . import kernels as K
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
 
 
+def stream_plan(n_chunks, max_streams=4, layout="lanes"):
+    """-> (pool size, YOLO stream, DINO stream, [stream of each SAM pass]) as indices into the stream pool.
+    "lanes": YOLO and DINO on a stream each, the SAM passes dealt over the remaining max_streams - 2 streams (two passes
+    in flight at the default of 4); "rr": everything dealt round-robin over max_streams streams."""
+    if layout not in ("lanes", "rr"):
+        raise ValueError(f"stream layout {layout!r}: expected 'lanes' or 'rr'")
+    k = max(3, min(2 + n_chunks, int(max_streams)))
+    if layout == "rr":
+        return k, 0, 1, [(2 + j) % k for j in range(n_chunks)]
+    return k, 0, 1, [2 + j % (k - 2) for j in range(n_chunks)]
+
+
 class FusedExtractor:
     def __init__(self, device="cuda", yolo_scale="l", weight_seeds=(7, 5, 3), yolo_bn=None):
         """Synthetic weights (no checkpoints exist offline): YOLOv8-{scale}, Hiera-B+, DINOv3 ViT-L/16."""
@@ -53,16 +65,9 @@ class FusedExtractor:
         if self.serial:
             det_stream, emb_stream, sam_streams = main, main, [main] * len(chunks)
         else:
-            # "lanes": YOLO and DINO on a stream each, the SAM chunks dealt over the remaining max_streams - 2 streams (two
-            # chunks in flight at the default of 4); "rr": everything dealt round-robin over max_streams streams
-            pool = self._streams(max(3, min(2 + len(chunks), self.max_streams)))
-            k = len(pool)
-            if self.stream_layout == "rr":
-                det_stream, emb_stream = pool[0], pool[1]
-                sam_streams = [pool[(2 + j) % k] for j in range(len(chunks))]
-            else:
-                det_stream, emb_stream = pool[0], pool[1]
-                sam_streams = [pool[2 + j % (k - 2)] for j in range(len(chunks))]
+            n_pool, di, ei, si = stream_plan(len(chunks), self.max_streams, self.stream_layout)
+            pool = self._streams(n_pool)
+            det_stream, emb_stream, sam_streams = pool[di], pool[ei], [pool[j] for j in si]
             for st in pool:
                 st.wait_stream(main)  # frames were produced on the caller's stream
         with torch.cuda.stream(det_stream):
