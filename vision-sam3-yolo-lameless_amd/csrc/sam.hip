@@ -161,7 +161,7 @@ __device__ __forceinline__ float sample_mid(const float* __restrict__ lg, int L,
 // DBG 0 is the product.  LMX_DBG_MASK (development only, tools/stream_race_probe.py): 1 = pass 2 reads the intermediate
 // with plain loads (the defect described at ld_mid); 2 = plain loads, and pass 1 counts its finished workgroups in
 // stats[7] while pass 2 counts in stats[15] the workgroups that started before that count was complete (never seen);
-// 3 = plain loads, system-scope release fence at the end of pass 1; 4 = plain loads, system-scope acquire fence at the start of pass 2; 5 = both fences
+// 3 = plain loads, system-scope release fence at the end of pass 1; 4 = plain loads, system-scope acquire fence at the start of pass 2; 5 = both fences; 6 / 7 = agent- / workgroup-scope loads in pass 2
 template <int DBG>
 __global__ __launch_bounds__(256) void mask_mid_kernel(const float* __restrict__ logits, float* __restrict__ mid, int n, int L,
                                                        int T, int nh, int nw, unsigned long long* dbg) {
@@ -190,6 +190,8 @@ __global__ __launch_bounds__(256) void mask_mid_kernel(const float* __restrict__
 template <int DBG>
 __device__ __forceinline__ float ld_mid(const float* p) {
   if (DBG == 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (DBG == 6) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // which cache level: agent scope
+  if (DBG == 7) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... workgroup scope
   return *p;
 }
 
@@ -445,6 +447,12 @@ extern "C" int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh,
   } else if (dbg == 4) {  // plain loads + acquire at the start of pass 2
     hipLaunchKernelGGL(mask_mid_kernel<4>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
     hipLaunchKernelGGL(mask_post_kernel<4>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+  } else if (dbg == 6) {
+    hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+    hipLaunchKernelGGL(mask_post_kernel<6>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+  } else if (dbg == 7) {
+    hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+    hipLaunchKernelGGL(mask_post_kernel<7>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
   } else if (dbg == 5) {  // plain loads + both fences
     hipLaunchKernelGGL(mask_mid_kernel<5>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
     hipLaunchKernelGGL(mask_post_kernel<5>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
