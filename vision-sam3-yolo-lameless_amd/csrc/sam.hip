@@ -161,7 +161,7 @@ __device__ __forceinline__ float sample_mid(const float* __restrict__ lg, int L,
 // DBG 0 is the product.  LMX_DBG_MASK (development only, tools/stream_race_probe.py): 1 = pass 2 reads the intermediate
 // with plain loads (the defect described at ld_mid); 2 = plain loads, and pass 1 counts its finished workgroups in
 // stats[7] while pass 2 counts in stats[15] the workgroups that started before that count was complete (never seen);
-// 3 = plain loads, system-scope release fence at the end of pass 1; 4 = plain loads, system-scope acquire fence at the start of pass 2; 5 = both fences; 6 / 7 = agent- / workgroup-scope loads in pass 2
+// 3 = plain loads, system-scope release fence at the end of pass 1; 4 = plain loads, system-scope acquire fence at the start of pass 2; 5 = both fences; 6 / 7 = agent- / workgroup-scope loads in pass 2; 8 = plain loads, s_waitcnt vmcnt(0) after every pixel's four loads
 template <int DBG>
 __global__ __launch_bounds__(256) void mask_mid_kernel(const float* __restrict__ logits, float* __restrict__ mid, int n, int L,
                                                        int T, int nh, int nw, unsigned long long* dbg) {
@@ -229,8 +229,10 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float* __restrict_
       int X0, X1;
       float lx;
       bil_idx(sx, x, nw, X0, X1, lx);
-      const float t0 = (1.f - lx) * ld_mid<DBG>(r0 + X0) + lx * ld_mid<DBG>(r0 + X1);
-      const float t1 = (1.f - lx) * ld_mid<DBG>(r1 + X0) + lx * ld_mid<DBG>(r1 + X1);
+      const float a00 = ld_mid<DBG>(r0 + X0), a01 = ld_mid<DBG>(r0 + X1), a10 = ld_mid<DBG>(r1 + X0), a11 = ld_mid<DBG>(r1 + X1);
+      if (DBG == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // plain loads, but never a partial vmcnt wait
+      const float t0 = (1.f - lx) * a00 + lx * a01;
+      const float t1 = (1.f - lx) * a10 + lx * a11;
       const float v = (1.f - ly) * t0 + ly * t1;
       if (v > 0.0f) {
         packed |= 1u << (8 * e);
@@ -447,6 +449,9 @@ extern "C" int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh,
   } else if (dbg == 4) {  // plain loads + acquire at the start of pass 2
     hipLaunchKernelGGL(mask_mid_kernel<4>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
     hipLaunchKernelGGL(mask_post_kernel<4>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+  } else if (dbg == 8) {
+    hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+    hipLaunchKernelGGL(mask_post_kernel<8>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
   } else if (dbg == 6) {
     hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
     hipLaunchKernelGGL(mask_post_kernel<6>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
