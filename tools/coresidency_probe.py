@@ -38,6 +38,16 @@ def background():
                     "attn_wide": (4096, 5, 80), "attn_1k": (1024, 7, 64)}[what]
         for _ in range(4 if T <= 128 else 1):
             K.attention(qkv[:, :H * hd], qkv[:, 448:448 + H * hd], qkv[:, 896:896 + H * hd], ao, 65536 // T, H, T, T, hd, 0.125)
+    elif what.startswith("a128_"):  # the 128-query-tile kernel with one operand collapsed onto a single row (row stride 0)
+        q_, k_, v_, o_ = qkv[:, :448], qkv[:, 448:896], qkv[:, 896:], ao
+        if what == "a128_o0":
+            o_ = ao[:1].expand(65536, 448)
+        elif what == "a128_q0":
+            q_ = qkv[:1, :448].expand(65536, 448)
+        elif what == "a128_kv0":
+            k_, v_ = qkv[:1, 448:896].expand(65536, 448), qkv[:1, 896:].expand(65536, 448)
+        for _ in range(4):
+            K.attention(q_, k_, v_, o_, 512, 7, 128, 128, 64, 0.125)
     elif what == "mm":  # a library GEMM: long-lived, LDS-heavy workgroups that are not ours
         torch.mm(big, big)
 
