@@ -138,9 +138,95 @@ def make_hiera(seed, clip_seed, frame_ids):
     print("hiera-b+ golden:", [tuple(f.shape) for f in fpn], "rms fpn2", float(fpn[2].pow(2).mean().sqrt()))
 
 
+def cfg2_frames(n=32, seed=1, size=640):
+    """BASELINE cfg#2 input: uniform u8 noise + 8 pasted solid rectangles per image, BGR u8 [n,640,640,3]."""
+    rng = np.random.default_rng(seed)
+    fr = rng.integers(0, 256, (n, size, size, 3), dtype=np.uint8)
+    for i in range(n):
+        for _ in range(8):
+            x0, y0 = (int(v) for v in rng.integers(0, size - 64, 2))
+            w, h = (int(v) for v in rng.integers(48, 320, 2))
+            fr[i, y0:min(size, y0 + h), x0:min(size, x0 + w)] = rng.integers(0, 256, 3, dtype=np.uint8)
+    return fr
+
+
+def make_yolo_cfg2(scale="l", seed=7, frame_ids=(0, 31)):
+    """fp32 oracle detections for two frames of the cfg#2 batch (YOLOv8-l, 640x640, batch 32).  Weights: seed 7 with the
+    committed BatchNorm statistics (SURVEY names seed 1; the calibrated statistics exist for seed 7 — same architecture)."""
+    from lmx import yolo
+    from oracle import yolo as OY
+
+    cfg = yolo.YoloConfig(scale)
+    sd = yolo.synthetic_state_dict(cfg, seed, os.path.join(HERE, f"yolov8{scale}_bn_w{seed}.npz"))
+    fr = cfg2_frames()
+    out = {"weight_seed": seed, "frame_ids": np.asarray(frame_ids)}
+    for j, fi in enumerate(frame_ids):
+        for conf in (0.25, 0.5):
+            r = OY.predict(scale, cfg.nc, sd, fr[fi], conf=conf)
+            tag = f"f{j}_c{int(conf * 100)}"
+            out[tag + "_boxes"], out[tag + "_scores"] = r["boxes"], r["scores"]
+            out[tag + "_cls"], out[tag + "_src"] = r["cls"], r["src"]
+        # what the keep-set margin rule (tests/keepset.py) needs of the fp32 prediction [8400, 84]: box, best score + class, runner-up
+        cs = r["pred"][:, 4:]
+        cls = cs.argmax(1)
+        best = cs[np.arange(len(cs)), cls]
+        tmp = cs.copy()
+        tmp[np.arange(len(cs)), cls] = -np.inf
+        out[f"f{j}_box"], out[f"f{j}_score"] = r["pred"][:, :4].astype(np.float32), best.astype(np.float32)
+        out[f"f{j}_cls"], out[f"f{j}_score2"] = cls.astype(np.int16), tmp.max(1).astype(np.float32)
+        print(f"cfg2 yolov8{scale} frame {fi}: {len(r['src'])} detections at conf 0.5, pred {r['pred'].shape}")
+    np.savez_compressed(os.path.join(HERE, f"yolov8{scale}_cfg2_w{seed}.npz"), **out)
+
+
+SAM_BOXES = np.array([[420.0, 360.0, 1010.0, 850.0], [1100.5, 380.25, 1700.0, 860.0]], np.float32)
+
+
+def make_sam_masks(kind, seed, clip_seed=6, frame_ids=(20, 100)):
+    """Raw 1080p frame -> mask through the fp32 oracle (set_image + predict(box), services/sam3-pipeline/app/main.py:80-88):
+    image encoder (Hiera-B+ = BASELINE cfg#3, or SAM v1 ViT-B = the reference's code path), prompt encoder, mask decoder,
+    post-processing.  Stored: the bit-packed mask (np.packbits), the low-res logits (f16), the IoU head and the box."""
+    from lmx import sam, sam_decoder
+    from oracle import sam_decoder as OD
+
+    frames = [synth.synth_frame(clip_seed, i) for i in frame_ids]
+    pv = torch.from_numpy(np.stack([OP.sam_pixel_values(f, 1024) for f in frames], 0))
+    dsd = sam_decoder.synthetic_state_dict(seed + 100)
+    with torch.no_grad():
+        if kind == "hiera_bplus":
+            from oracle import hiera as OH
+
+            cfg = sam.hiera_b_plus()
+            sd = weights.synth_state_dict(sam.param_spec(cfg), seed)
+            emb = OH.encoder_forward(cfg, sd, pv)[0][2]
+        else:
+            from oracle import sam_vit as OV
+
+            cfg = sam.sam_vit_b()
+            sd = weights.synth_state_dict(sam.vit_param_spec(cfg), seed)
+            emb = OV.encoder_forward(cfg, sd, pv)
+        hw = frames[0].shape[:2]
+        rhw = sam.resize_longest_side(hw[0], hw[1], 1024)
+        sp = OD.prompt_encode_box(dsd, torch.from_numpy(OD.scale_box(SAM_BOXES, hw, rhw)))
+        low, iou = OD.mask_decode(dsd, emb, sp)
+        mask = OD.postprocess(low, rhw, hw).numpy()
+    cov = mask.reshape(len(frames), -1).mean(1)
+    print(f"sam mask golden {kind}: coverage {cov.tolist()}, iou head {iou.tolist()}, emb rms {float(emb.pow(2).mean().sqrt()):.3f}")
+    np.savez_compressed(os.path.join(HERE, f"sam_mask_{kind}_w{seed}.npz"), weight_seed=seed, clip_seed=clip_seed,
+                        frame_ids=np.asarray(frame_ids), boxes=SAM_BOXES, mask_bits=np.packbits(mask, axis=-1),
+                        lowres=low.numpy().astype(np.float16), iou=iou.numpy(), coverage=cov,
+                        emb_sub=emb.permute(0, 2, 3, 1)[:, ::4, ::4].numpy().astype(np.float16))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "hiera":
         make_hiera(5, 6, [20])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg2":
+        make_yolo_cfg2()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sam_masks":
+        make_sam_masks("hiera_bplus", 5)
+        make_sam_masks("vit_b", 9)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pose":
         make_yolo_pose("n", 7, 2, [(3, 40), (2, 50)])
@@ -152,3 +238,6 @@ if __name__ == "__main__":
     make_dino("dinov3_vitl16_w3", dino.dinov3_vitl16(), 3, [0, 75, 149], clip_seed=4)
     make_dino("dinov2_base_w4", dino.dinov2_base(), 4, [0, 30], clip_seed=5)
     make_hiera(5, 6, [20])
+    make_yolo_cfg2()
+    make_sam_masks("hiera_bplus", 5)
+    make_sam_masks("vit_b", 9)

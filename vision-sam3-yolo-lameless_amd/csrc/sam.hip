@@ -437,37 +437,29 @@ extern "C" int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh,
   hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, st, reinterpret_cast<long long*>(stats), n);
   int gx = (int)(((int64_t)h * ((w + 3) / 4) + 255) / 256);
   if (gx > 96) gx = 96;  // 96 blocks x n frames: >= 3000 blocks at the bench batch, and only 96 x 7 atomics per frame
-  static const int dbg = getenv("LMX_DBG_MASK") ? atoi(getenv("LMX_DBG_MASK")) : 0;
   const unsigned gmid = grid_for((int64_t)n * nh * nw);
   unsigned long long* su = reinterpret_cast<unsigned long long*>(stats);
-  if (dbg == 2 && n >= 2) {
-    hipLaunchKernelGGL(mask_mid_kernel<2>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
-    hipLaunchKernelGGL(mask_post_kernel<2>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
-  } else if (dbg == 3) {  // plain loads + release at the end of pass 1
-    hipLaunchKernelGGL(mask_mid_kernel<3>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
-    hipLaunchKernelGGL(mask_post_kernel<3>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
-  } else if (dbg == 4) {  // plain loads + acquire at the start of pass 2
-    hipLaunchKernelGGL(mask_mid_kernel<4>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
-    hipLaunchKernelGGL(mask_post_kernel<4>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
-  } else if (dbg == 8) {
-    hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
-    hipLaunchKernelGGL(mask_post_kernel<8>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
-  } else if (dbg == 6) {
-    hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
-    hipLaunchKernelGGL(mask_post_kernel<6>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
-  } else if (dbg == 7) {
-    hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
-    hipLaunchKernelGGL(mask_post_kernel<7>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
-  } else if (dbg == 5) {  // plain loads + both fences
-    hipLaunchKernelGGL(mask_mid_kernel<5>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
-    hipLaunchKernelGGL(mask_post_kernel<5>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
-  } else if (dbg == 1) {
-    hipLaunchKernelGGL(mask_mid_kernel<1>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
-    hipLaunchKernelGGL(mask_post_kernel<1>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
-  } else {
-    hipLaunchKernelGGL(mask_mid_kernel<0>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
-    hipLaunchKernelGGL(mask_post_kernel<0>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+#ifdef LMX_DBG_VARIANTS  // development build only (make dbg -> liblmx_dbg.so): the probes of DESIGN.md section 6
+  static const int dbg = getenv("LMX_DBG_MASK") ? atoi(getenv("LMX_DBG_MASK")) : 0;
+#define LMX_MASK_VARIANT(M, P)                                                                                         \
+  {                                                                                                                    \
+    hipLaunchKernelGGL(mask_mid_kernel<M>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);      \
+    hipLaunchKernelGGL(mask_post_kernel<P>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid); \
   }
+  if (dbg == 2 && n >= 2) LMX_MASK_VARIANT(2, 2)
+  else if (dbg == 3) LMX_MASK_VARIANT(3, 3)  // plain loads + release at the end of pass 1
+  else if (dbg == 4) LMX_MASK_VARIANT(4, 4)  // plain loads + acquire at the start of pass 2
+  else if (dbg == 5) LMX_MASK_VARIANT(5, 5)  // plain loads + both fences
+  else if (dbg == 8) LMX_MASK_VARIANT(1, 8)
+  else if (dbg == 6) LMX_MASK_VARIANT(1, 6)
+  else if (dbg == 7) LMX_MASK_VARIANT(1, 7)
+  else if (dbg == 1) LMX_MASK_VARIANT(1, 1)
+  else LMX_MASK_VARIANT(0, 0)
+#undef LMX_MASK_VARIANT
+#else
+  hipLaunchKernelGGL(mask_mid_kernel<0>, dim3(gmid), dim3(256), 0, st, logits, workspace, n, L, T, nh, nw, su);
+  hipLaunchKernelGGL(mask_post_kernel<0>, dim3(gx, n), dim3(256), 0, st, workspace, n, nh, nw, h, w, mask, su, gmid);
+#endif
   return lmx_launch_check("mask_post_kernel");
 }
 

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblmx.so")
+# LMX_LIB: development builds only (csrc/Makefile `dbg`); the product loads the in-tree liblmx.so
+LIB_PATH = os.environ.get("LMX_LIB") or os.path.join(_HERE, "liblmx.so")
 
 
 class LmxError(RuntimeError):
