@@ -138,18 +138,6 @@ def make_hiera(seed, clip_seed, frame_ids):
     print("hiera-b+ golden:", [tuple(f.shape) for f in fpn], "rms fpn2", float(fpn[2].pow(2).mean().sqrt()))
 
 
-def cfg2_frames(n=32, seed=1, size=640):
-    """BASELINE cfg#2 input: uniform u8 noise + 8 pasted solid rectangles per image, BGR u8 [n,640,640,3]."""
-    rng = np.random.default_rng(seed)
-    fr = rng.integers(0, 256, (n, size, size, 3), dtype=np.uint8)
-    for i in range(n):
-        for _ in range(8):
-            x0, y0 = (int(v) for v in rng.integers(0, size - 64, 2))
-            w, h = (int(v) for v in rng.integers(48, 320, 2))
-            fr[i, y0:min(size, y0 + h), x0:min(size, x0 + w)] = rng.integers(0, 256, 3, dtype=np.uint8)
-    return fr
-
-
 def make_yolo_cfg2(scale="l", seed=7, frame_ids=(0, 31)):
     """fp32 oracle detections for two frames of the cfg#2 batch (YOLOv8-l, 640x640, batch 32).  Weights: seed 7 with the
     committed BatchNorm statistics (SURVEY names seed 1; the calibrated statistics exist for seed 7 — same architecture)."""
@@ -158,7 +146,7 @@ def make_yolo_cfg2(scale="l", seed=7, frame_ids=(0, 31)):
 
     cfg = yolo.YoloConfig(scale)
     sd = yolo.synthetic_state_dict(cfg, seed, os.path.join(HERE, f"yolov8{scale}_bn_w{seed}.npz"))
-    fr = cfg2_frames()
+    fr = synth.cfg2_frames()
     out = {"weight_seed": seed, "frame_ids": np.asarray(frame_ids)}
     for j, fi in enumerate(frame_ids):
         for conf in (0.25, 0.5):

@@ -41,10 +41,31 @@ def test_fused_service_end_to_end(cuda, tmp_path):
     seg = SP.HieraSegmenter(sam.HieraEncoder(hcfg, hsd, cuda), sam_decoder.MaskDecoder(msd, cuda))
     s = services.SAM3Pipeline(seg, bus, cfg, results_dir=tmp_path / "sam3", yolo_results_dir=tmp_path / "yolo")
     d = services.DINOv3Pipeline(dino.DinoEmbedder(dcfg, dsd, cuda), bus, None, cfg, results_dir=tmp_path / "dino")
-    fused = services.FusedFeatureService(y, s, d)
-    asyncio.run(fused.start())
-    asyncio.run(bus.publish("video.preprocessed", {"video_id": "clip1", "processed_path": str(clip), "filename": "clip1.mp4"}))
-    assert [p[0] for p in bus.published] == ["video.preprocessed", "pipeline.yolo", "pipeline.sam3", "pipeline.dinov3"]
+    msg = {"video_id": "clip1", "processed_path": str(clip), "filename": "clip1.mp4"}
+    for svc in (y, s, d):  # the three services one after the other, as the product runs them
+        asyncio.run(svc.process_video(msg))
+    assert [p[0] for p in bus.published] == ["pipeline.yolo", "pipeline.sam3", "pipeline.dinov3"]
+    # the fused service: ONE decode, overlapped uploads, FusedExtractor.step per chunk -> the same three files, byte for byte
+    from lmx import pipeline
+
+    bus2 = R.InProcessBus()
+    y2 = services.YOLOPipeline(y.yolo_model, bus2, cfg, results_dir=tmp_path / "f_yolo")
+    s2 = services.SAM3Pipeline(seg, bus2, cfg, results_dir=tmp_path / "f_sam3", yolo_results_dir=tmp_path / "f_yolo")
+    d2 = services.DINOv3Pipeline(d.model, bus2, None, cfg, results_dir=tmp_path / "f_dino")
+    fx = pipeline.FusedExtractor.from_models(y.yolo_model, seg.encoder, seg.decoder, d.model)
+    for schedule, chunk in (("reference", 2), ("dense", 4)):
+        fused = services.FusedFeatureService(fx, y2, s2, d2, schedule=schedule, chunk=chunk)
+        bus2.published.clear()
+        bus2.handlers.clear()
+        asyncio.run(fused.start())
+        asyncio.run(bus2.publish("video.preprocessed", msg))
+        assert [p[0] for p in bus2.published] == ["video.preprocessed", "pipeline.yolo", "pipeline.sam3", "pipeline.dinov3"]
+        for a, b in (("yolo/clip1_yolo.json", "f_yolo/clip1_yolo.json"), ("sam3/clip1_sam3.json", "f_sam3/clip1_sam3.json"),
+                     ("dino/clip1_dinov3.json", "f_dino/clip1_dinov3.json")):
+            ja, jb = json.load(open(tmp_path / a)), json.load(open(tmp_path / b))
+            if "dinov3" in a:  # the second run finds the first run's vector in the store: compare the rest
+                ja.pop("similar_cases"), jb.pop("similar_cases"), ja.pop("neighbor_evidence"), jb.pop("neighbor_evidence")
+            assert ja == jb, f"fused ({schedule}) and separate services disagree on {a}"
 
     yj = json.load(open(tmp_path / "yolo" / "clip1_yolo.json"))
     sj = json.load(open(tmp_path / "sam3" / "clip1_sam3.json"))

@@ -11,8 +11,13 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import keepset as KS
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# caps on the measured deviation of the f16 network from the fp32 oracle near the thresholds (synthetic random weights,
+# ~60 layers of f16 activation storage); the tests print the measured values, the margin rule uses the measured ones
+EPS_SCORE_CAP, EPS_IOU_CAP = 2.5e-2, 8e-2
 
 
 def _rand(shape, seed, scale=1.0):
@@ -76,12 +81,6 @@ def test_stem_pool_upsample_decode(cuda):
     assert float(pred[:, :7].abs().max()) == 0
 
 
-def _compare_detections(det, ref, conf, label):
-    """det/ref: dict(src, boxes, scores, cls).  Returns (n_common, n_only_gpu, n_only_ref)."""
-    a, b = set(det["src"].tolist()), set(ref["src"].tolist())
-    return len(a & b), len(a - b), len(b - a)
-
-
 @pytest.mark.parametrize("scale,frames", [("n", [(3, 40), (2, 50), (4, 0)]), ("l", [(3, 40), (2, 50)])])
 def test_yolo_end_to_end(cuda, scale, frames):
     from lmx import kernels as K
@@ -115,6 +114,7 @@ def test_yolo_end_to_end(cuda, scale, frames):
         assert dbox < 4.0, f"frame {j}: box coords off by {dbox} px (letterboxed)"
         assert dcls < 2e-2, f"frame {j}: class scores off by {dcls}"
         report.append(("pred", j, float(ebox), float(ecls), float(dbox), float(dcls)))
+        ref_nms = {c: ONMS.non_max_suppression(ref["pred"], c) for c in (0.25, 0.5)}
         assert np.allclose(ref["pred"][::97], gold[f"f{j}_pred_sample"], atol=1e-4), "oracle drifted from golden"
         for conf in (0.25, 0.5):
             # (2) NMS on the GPU's own prediction tensor: bit-exact against the oracle NMS
@@ -123,21 +123,24 @@ def test_yolo_end_to_end(cuda, scale, frames):
             k = len(rsrc)
             assert cnt[0] == k and np.array_equal(src[0, :k], rsrc) and np.array_equal(c[0, :k], rc)
             assert np.array_equal(b[0, :k], rb) and np.array_equal(s[0, :k], rs)
-            # (3) end to end vs the fp32 oracle (golden): borderline candidates counted
+            # (3) end to end vs the fp32 oracle: the keep-set (anchor indices = box indices) must be IDENTICAL to the fp32
+            # one after removing only the candidates the margin rule lists as ambiguous at the MEASURED deviation of this
+            # frame's device prediction (tests/keepset.py); any unexplained difference fails
             g_src = gold[f"f{j}_c{int(conf * 100)}_src"]
-            common = len(set(rsrc.tolist()) & set(g_src.tolist()))
-            union = len(set(rsrc.tolist()) | set(g_src.tolist()))
-            jac = common / union if union else 1.0
-            margin = np.abs(ref["pred"][:, 4:].max(1) - conf) < 5e-3
-            report.append((j, conf, k, len(g_src), jac, int(margin.sum())))
-            assert jac >= 0.8, f"frame {j} conf {conf}: keep-set Jaccard {jac:.3f} ({k} vs {len(g_src)})"
+            assert np.array_equal(ref_nms[conf][3], g_src), "oracle keep-set drifted from the committed golden"
+            cref, cdev = KS.compact_pred(ref["pred"]), KS.compact_pred(pred_c[j])
+            eps_s, eps_i, n_meas = KS.measure_eps(cref, cdev, conf)
+            assert eps_s <= EPS_SCORE_CAP and eps_i <= EPS_IOU_CAP, f"frame {j} conf {conf}: f16 deviation eps_score {eps_s} eps_iou {eps_i}"
+            rep = KS.check_keepset(cref, conf, 0.7, eps_s, eps_i, rsrc, rc, f"yolov8{scale} frame {j} conf {conf}")
+            report.append((j, conf, rep["n_dev"], len(g_src), rep["n_firm"], rep["n_ambiguous"], float(eps_s), float(eps_i)))
+            assert rep["n_firm"] >= 0.5 * len(g_src) or len(g_src) < 4, f"margin too wide to mean anything: {rep} vs {len(g_src)} fp32 detections"
             if len(g_src) and k:
                 # the detection SAM is prompted with (first = highest confidence) must be the same anchor unless
-                # the fp32 top-2 scores are within 1e-2 of each other
+                # the fp32 top-2 scores are within 2 * eps_score of each other
                 gs = gold[f"f{j}_c{int(conf * 100)}_scores"]
-                if len(gs) < 2 or gs[0] - gs[1] > 1e-2:
+                if len(gs) < 2 or gs[0] - gs[1] > 2 * eps_s:
                     assert rsrc[0] == g_src[0], f"frame {j}: top-1 detection differs"
-    print("yolo", scale, "(frame, conf, kept_gpu, kept_fp32, jaccard, n_within_5e-3_of_conf):", report)
+    print("yolo", scale, "(frame, conf, kept_gpu, kept_fp32, firm, ambiguous, eps_score, eps_iou):", report)
     # full detect() path incl. scale_boxes on the batch
     boxes, scores, cls, src, counts = det.detect(d_fr, conf=0.5)
     torch.cuda.synchronize()
@@ -235,3 +238,60 @@ def test_pose_end_to_end(cuda):
         gy = (got_raw[..., 1] * 2 + cy[:, None]) * strd[:, None]
         e = max(float(np.abs(gx - dec[..., 0]).max()), float(np.abs(gy - dec[..., 1]).max()))
         assert e < 1.5, f"frame {j}: keypoint head disagrees with the f16-storage emulation by {e} letterboxed px"
+
+
+def test_cfg2_yolov8l_640x640_batch32(cuda):
+    """BASELINE cfg#2: YOLOv8-l on [32,640,640,3] (no letterbox padding: 640x640 frames map 1:1).  The two golden frames
+    (indices 0 and 31 of the batch) pass the keep-set margin rule against the committed fp32 oracle prediction; NMS on the
+    device prediction is bit-exact against the oracle NMS for every frame of the batch; a second run of the whole batch is
+    bit-identical; frames of the batch do not influence each other (frame 31 alone == frame 31 in the batch)."""
+    from lmx import kernels as K
+    from lmx import synth, yolo
+    from oracle import nms as ONMS
+
+    g = np.load(os.path.join(GOLD, "yolov8l_cfg2_w7.npz"))
+    cfg = yolo.YoloConfig("l")
+    sd = yolo.synthetic_state_dict(cfg, int(g["weight_seed"]), os.path.join(GOLD, "yolov8l_bn_w7.npz"))
+    det = yolo.YoloDetector(cfg, sd, cuda)
+    fr = synth.cfg2_frames()
+    assert fr.shape == (32, 640, 640, 3)
+    d_fr = torch.from_numpy(fr).to(cuda)
+    img, geo = det.preprocess(d_fr)
+    assert tuple(img.shape) == (32, 640, 640, 3) and (geo.pad_x, geo.pad_y) == (0, 0)
+    assert torch.equal(img, d_fr.flip(-1)), "640x640 input: letterbox must be the identity (BGR->RGB only)"
+    pred = det.forward_letterboxed(img)
+    torch.cuda.synchronize()
+    assert tuple(pred.shape) == (32, 8400, 84)
+    pred_c = pred.cpu().numpy()
+    assert np.isfinite(pred_c).all()
+    report = []
+    for conf in (0.25, 0.5):
+        b, s, c, src, cnt = (t.cpu().numpy() for t in K.nms(pred, conf))
+        for i in range(32):  # NMS kernel vs oracle NMS on the same (device) prediction: bit-exact, every frame
+            rb, rs, rc, rsrc = ONMS.non_max_suppression(pred_c[i], conf)
+            k = len(rsrc)
+            assert cnt[i] == k and np.array_equal(src[i, :k], rsrc) and np.array_equal(c[i, :k], rc), f"frame {i} conf {conf}"
+            assert np.array_equal(b[i, :k], rb) and np.array_equal(s[i, :k], rs)
+        for j, fi in enumerate(g["frame_ids"]):  # the golden frames vs the fp32 oracle
+            cref = dict(box=g[f"f{j}_box"], score=g[f"f{j}_score"], cls=g[f"f{j}_cls"], score2=g[f"f{j}_score2"])
+            cdev = KS.compact_pred(pred_c[fi])
+            eps_s, eps_i, _ = KS.measure_eps(cref, cdev, conf)
+            assert eps_s <= EPS_SCORE_CAP and eps_i <= EPS_IOU_CAP, f"frame {fi}: eps_score {eps_s} eps_iou {eps_i}"
+            k = int(cnt[fi])
+            rep = KS.check_keepset(cref, conf, 0.7, eps_s, eps_i, src[fi, :k], c[fi, :k], f"cfg2 frame {fi} conf {conf}")
+            n_gold = len(g[f"f{j}_c{int(conf * 100)}_src"])
+            report.append((int(fi), conf, k, n_gold, rep["n_firm"], rep["n_ambiguous"], float(eps_s), float(eps_i)))
+            assert rep["n_firm"] >= 0.5 * n_gold
+    print("cfg2 (frame, conf, kept_gpu, kept_fp32, firm, ambiguous, eps_score, eps_iou):", report)
+    # bit-reproducible, and batch-independent
+    pred2 = det.forward_letterboxed(img)
+    torch.cuda.synchronize()
+    assert torch.equal(pred, pred2), "cfg#2 forward is not bit-reproducible"
+    alone = det.forward_letterboxed(img[31:32])
+    assert torch.equal(alone[0], pred[31]), "frame 31 alone differs from frame 31 inside the batch of 32"
+    # the service-level call on the batch
+    boxes, scores, cls, src2, counts = det.detect(d_fr, conf=0.5)
+    torch.cuda.synchronize()
+    b, s, c, src, cnt = (t.cpu().numpy() for t in K.nms(pred, 0.5))
+    assert np.array_equal(counts.cpu().numpy(), cnt) and np.array_equal(src2.cpu().numpy(), src)
+    assert np.allclose(boxes.cpu().numpy(), np.clip(b, 0, 640), atol=1e-4)  # gain 1, no padding: scale_boxes only clips

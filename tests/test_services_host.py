@@ -151,19 +151,146 @@ def test_dinov3_schema_and_neighbor_evidence(tmp_path):
     assert subj == "pipeline.dinov3" and list(payload) == ["video_id", "pipeline", "results_path", "neighbor_evidence", "similar_cases", "embedding_dim"]
 
 
-def test_fused_order(tmp_path):
-    path = _clip(tmp_path, 31, 30.0)
-    bus = R.InProcessBus()
-    det = FakeDetector(lambda fid: [([2, 2, 20, 20], 0.9, 19)])
-    y = services.YOLOPipeline(det, bus, _cfg(), results_dir=tmp_path / "yolo")
-    s = services.SAM3Pipeline(None, bus, _cfg(), results_dir=tmp_path / "sam3", yolo_results_dir=tmp_path / "yolo")
-    d = services.DINOv3Pipeline(FakeEmbedder(), bus, None, _cfg(), results_dir=tmp_path / "dino")
-    fused = services.FusedFeatureService(y, s, d)
+class FakeExtractor:
+    """CPU stand-in for lmx.pipeline.FusedExtractor: FakeDetector boxes, the rectangle of the first box as the mask (what
+    SAM3Pipeline(None) falls back to), FakeEmbedder embeddings; same step() surface and record fields."""
+    device = torch.device("cpu")
+
+    def __init__(self, det, emb):
+        self.det, self.emb = det, emb
+        self.yolo = det
+        self.steps = []
+
+    class dino:
+        class cfg:
+            hidden = 8
+
+    def step(self, frames, conf=0.5, det_idx=None, emb_idx=None, **_):
+        from lmx.services.sam3_pipeline import fallback_segmentation
+
+        n, h, w, _c = frames.shape
+        di = list(range(n)) if det_idx is None else list(det_idx)
+        ei = list(range(n)) if emb_idx is None else list(emb_idx)
+        self.steps.append((n, len(di), len(ei)))
+        out = dict(boxes=torch.zeros((n, 300, 4)), scores=torch.zeros((n, 300)), cls=torch.zeros((n, 300), dtype=torch.int32),
+                   counts=torch.zeros((n,), dtype=torch.int32), embedding=torch.zeros((n, 8)),
+                   mask_bits=torch.zeros((n, h, (w + 7) // 8), dtype=torch.uint8), mask_stats=torch.zeros((n, 8), dtype=torch.int64),
+                   mask_iou=torch.zeros((n,)), ran_det=torch.zeros((n,), dtype=torch.int32), ran_emb=torch.zeros((n,), dtype=torch.int32))
+        if di:
+            b, s, c, _x, k = self.det.detect(frames[di], conf=conf)
+            for jj, j in enumerate(di):
+                out["boxes"][j], out["scores"][j], out["cls"][j], out["counts"][j] = b[jj], s[jj], c[jj], k[jj]
+                if int(k[jj]):
+                    m = fallback_segmentation((h, w), b[jj, 0].tolist())
+                    out["mask_bits"][j] = torch.from_numpy(np.packbits(m, axis=-1))
+                out["ran_det"][j] = 1
+        if ei:
+            e = self.emb.embed_frames(frames[ei])
+            for jj, j in enumerate(ei):
+                out["embedding"][j] = e[jj]
+                out["ran_emb"][j] = 1
+        return out
+
+
+def _three_and_fused(tmp_path, tag, bus, per_frame, schedule="reference", chunk=4):
+    det = FakeDetector(per_frame)
+    y = services.YOLOPipeline(det, bus, _cfg(), results_dir=tmp_path / tag / "yolo")
+    s = services.SAM3Pipeline(None, bus, _cfg(), results_dir=tmp_path / tag / "sam3", yolo_results_dir=tmp_path / tag / "yolo")
+    d = services.DINOv3Pipeline(FakeEmbedder(), bus, None, _cfg(), results_dir=tmp_path / tag / "dino")
+    fx = FakeExtractor(FakeDetector(per_frame), FakeEmbedder())
+    return y, s, d, services.FusedFeatureService(fx, y, s, d, schedule=schedule, chunk=chunk), fx
+
+
+def _load3(root, vid):
+    return [json.load(open(root / n / f"{vid}_{k}.json")) for n, k in (("yolo", "yolo"), ("sam3", "sam3"), ("dino", "dinov3"))]
+
+
+@pytest.mark.parametrize("fps,n_frames,schedule", [(30.0, 95, "reference"), (25.0, 60, "reference"), (30.0, 47, "dense")])
+def test_fused_service_equals_the_three_services(tmp_path, monkeypatch, fps, n_frames, schedule):
+    """One open + one decode pass, three JSONs identical to what the three services write (fps 25: the DINO schedule
+    25, 50 is NOT a subset of the YOLO/SAM schedule 0, 12, 24, ...), subjects in the order yolo -> sam3 -> dinov3."""
+    path = _clip(tmp_path, n_frames, fps)
+    per_frame = (lambda fid: [([2 + fid % 5, 2, 20 + fid % 7, 22], 0.9, 19), ([1, 1, 5, 5], 0.7, 0)] if fid not in (12, 30, 60) else [])
+    bus_a, bus_b = R.InProcessBus(), R.InProcessBus()
+    y, s, d, _, _ = _three_and_fused(tmp_path, "sep", bus_a, per_frame)
+    msg = {"video_id": "z", "processed_path": str(path), "filename": "z.mp4"}
+    for svc in (y, s, d):
+        _run(svc.process_video(msg))
+    _, _, _, fused, fx = _three_and_fused(tmp_path, "fused", bus_b, per_frame, schedule)
+    opens, passes = [], []
+    real_open, real_iter = R.Clip.open, R.Clip.iter_frames
+    monkeypatch.setattr(R.Clip, "open", staticmethod(lambda p: (opens.append(p), real_open(p))[1]))
+    monkeypatch.setattr(R.Clip, "iter_frames", lambda self, keep=None: (passes.append(1), real_iter(self, keep))[1])
     _run(fused.start())
-    _run(bus.publish("video.preprocessed", {"video_id": "z", "processed_path": str(path)}))
-    assert [p[0] for p in bus.published] == ["video.preprocessed", "pipeline.yolo", "pipeline.sam3", "pipeline.dinov3"]
-    sam = json.load(open(tmp_path / "sam3" / "z_sam3.json"))
-    assert all(sg["mask_available"] for sg in sam["segmentations"])  # YOLO ran first: no race
+    _run(bus_b.publish("video.preprocessed", msg))
+    assert len(opens) == 1 and len(passes) == 1, "the fused service must open and decode the clip once"
+    assert [p[0] for p in bus_b.published] == ["video.preprocessed", "pipeline.yolo", "pipeline.sam3", "pipeline.dinov3"]
+    sep, fu = _load3(tmp_path / "sep", "z"), _load3(tmp_path / "fused", "z")
+    assert sep == fu
+    for (sa, pa), (sb, pb) in zip(bus_a.published, bus_b.published[1:]):
+        assert sa == sb and {k: v for k, v in pa.items() if k != "results_path"} == {k: v for k, v in pb.items() if k != "results_path"}
+    if schedule == "reference":  # every chunk carries only scheduled frames, and DINO runs on its own (sparser) schedule
+        i_det, i_emb = max(1, int(fps) // 2), max(1, int(fps))
+        union = sorted(set(range(0, n_frames, i_det)) | set(range(0, n_frames, i_emb)))
+        assert sum(n for n, _, _ in fx.steps) == len(union)
+        assert sum(k for _, k, _ in fx.steps) == len(range(0, n_frames, i_det)) and sum(k for _, _, k in fx.steps) == len(range(0, n_frames, i_emb))
+    else:
+        assert sum(n for n, _, _ in fx.steps) == n_frames
+    sam = fu[1]
+    assert any(sg["mask_available"] for sg in sam["segmentations"]) and not all(sg["mask_available"] for sg in sam["segmentations"])
+
+
+def test_clip_streams_and_keeps_only_sampled_frames(tmp_path, monkeypatch):
+    """A video file is read like the reference's cap.read() loop: one decoded frame alive at a time, only sampled frames kept
+    (the round-1 reader stacked every frame of the clip: 56 GB for five minutes of 1080p)."""
+    import sys
+    import types
+    import weakref
+
+    alive, peak = [0], [0]
+
+    def _gone():
+        alive[0] -= 1
+
+    class Frame(np.ndarray):
+        pass
+
+    class Cap:
+        def __init__(self, path):
+            self.i, self.n = 0, 301
+
+        def isOpened(self):
+            return True
+
+        def get(self, prop):
+            return {5: 29.97, 7: 300, 3: 64, 4: 48}[prop]  # metadata says 300, the stream holds 301 (cv2 does that)
+
+        def read(self):
+            if self.i >= self.n:
+                return False, None
+            f = np.zeros((48, 64, 3), np.uint8).view(Frame)
+            f[0, 0, 0] = self.i % 256
+            alive[0] += 1
+            weakref.finalize(f, _gone)
+            peak[0] = max(peak[0], alive[0])
+            self.i += 1
+            return True, f
+
+        def release(self):
+            pass
+
+    cv2 = types.SimpleNamespace(VideoCapture=Cap, CAP_PROP_FPS=5, CAP_PROP_FRAME_COUNT=7, CAP_PROP_FRAME_WIDTH=3, CAP_PROP_FRAME_HEIGHT=4)
+    monkeypatch.setitem(sys.modules, "cv2", cv2)
+    clip = R.Clip.open(str(tmp_path / "video.mp4"))
+    assert (clip.fps, clip.total_frames, clip.frame_hw) == (29, 300, (48, 64))
+    got = []
+    for ids, frames in clip.batches((14, 29), 8):
+        assert frames.dtype == np.uint8 and frames.shape[1:] == (48, 64, 3) and len(ids) <= 8
+        got += ids
+        assert [int(v) for v in frames[:, 0, 0, 0]] == [i % 256 for i in ids]
+    want = sorted(set(range(0, 301, 14)) | set(range(0, 301, 29)))
+    assert got == want and clip.n_decoded == 301
+    assert peak[0] <= 8 + 2, f"{peak[0]} decoded frames were alive at once"
 
 
 def test_clip_curation_best_detection_rule():
@@ -186,10 +313,10 @@ def test_clip_curation_best_detection_rule():
 
 
 def test_stream_plan_layouts():
-    """FusedExtractor's stream assignment: at most two SAM passes in flight by default."""
+    """FusedExtractor's stream assignment (the product default is max_streams = 6: four SAM passes in flight)."""
     from lmx.pipeline import stream_plan
 
-    assert stream_plan(4) == (4, 0, 1, [2, 3, 2, 3])               # bench batch: 64 frames, passes of 16
+    assert stream_plan(4) == (4, 0, 1, [2, 3, 2, 3])               # 64 frames, passes of 16, at most 4 streams
     assert stream_plan(2) == (4, 0, 1, [2, 3])
     assert stream_plan(1) == (3, 0, 1, [2])
     assert stream_plan(4, 6) == (6, 0, 1, [2, 3, 4, 5])

@@ -258,15 +258,16 @@ class DinoEmbedder:
             self._tabs[key] = (nh, nw, th, tv)
         return self._tabs[key]
 
-    def preprocess(self, frames_bgr):
-        """u8 [B,H,W,3] BGR (cv2 order) on device -> f16 patch matrix [B*np, k_pad]:
+    def preprocess(self, frames_bgr, rgb=False):
+        """u8 [B,H,W,3] BGR (cv2 order; `rgb=True`: already RGB, as the PIL image the glue hands the processor) on device
+        -> f16 patch matrix [B*np, k_pad]:
         cvtColor(BGR2RGB) -> PIL bicubic shortest-edge resize -> center crop -> /255 -> ImageNet normalise."""
         cfg = self.cfg
         B, h, w, _ = frames_bgr.shape
         nh, nw, th, tv = self._tables(h, w)
         if nh < cfg.image or nw < cfg.image:
             raise K.LmxError(f"frame {h}x{w} resizes to {nh}x{nw}, smaller than the {cfg.image} crop")
-        img = K.pil_resize(frames_bgr, nw, nh, th, tv, swap_rb=True)
+        img = K.pil_resize(frames_bgr, nw, nh, th, tv, swap_rb=not rgb)
         top, left = (nh - cfg.image) // 2, (nw - cfg.image) // 2
         return K.patchify_norm(img, top, left, cfg.grid, cfg.grid, cfg.patch, self.lut, k_pad=self.k_pad)
 

@@ -13,8 +13,12 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
 _DT = {torch.float16: F16, torch.float32: F32}
 
 
+_cur_dev = None  # device of the operands of the wrapper that is being executed (set by _dev, read by _stream)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The HIP stream the launch goes to: torch's current stream OF THE OPERANDS' DEVICE (not of the current device)."""
+    return C.c_void_p(torch.cuda.current_stream(_cur_dev).cuda_stream)
 
 
 def _ptr(t):
@@ -22,9 +26,20 @@ def _ptr(t):
 
 
 def _dev(*ts):
+    """Every operand must live in HBM, all on one device; remembers that device for _stream()."""
+    global _cur_dev
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise LmxError("lmx kernels take device (HBM) tensors only; got a CPU tensor")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise LmxError(f"lmx kernels: operands on different devices ({dev} and {t.device})")
+    if dev is not None:
+        _cur_dev = dev
 
 
 def _rows(t, what):

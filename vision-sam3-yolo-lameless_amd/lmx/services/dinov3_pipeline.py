@@ -27,19 +27,22 @@ class DINOv3Pipeline:
         except Exception as e:  # noqa: BLE001 — main.py:92-93 prints and carries on
             print(f"Error ensuring collection: {e}")
 
+    @staticmethod
+    def embeddings_result(embs, total, fps):
+        """main.py:143-163: the embedding list plus canonical frames [first, middle, last]."""
+        canonical = [embs[0], embs[len(embs) // 2], embs[-1]] if embs else []
+        return {"embeddings": embs, "canonical_frames": canonical, "total_frames": total, "fps": fps}
+
     def extract_video_embeddings(self, video_path):
         clip = R.Clip.open(video_path)
         fps, total = clip.fps, clip.total_frames
-        ids = R.sampled(len(clip.frames), max(1, fps))
         embs = []
         dev = self.model.device
-        for i in range(0, len(ids), self.batch):
-            chunk = ids[i:i + self.batch]
-            e = self.model.embed_frames(torch.from_numpy(np.ascontiguousarray(clip.frames[chunk])).to(dev)).cpu().numpy()
+        for chunk, host in clip.batches(max(1, fps), self.batch):
+            e = self.model.embed_frames(torch.from_numpy(host).to(dev)).cpu().numpy()
             for fid, v in zip(chunk, e):
                 embs.append({"frame": fid, "time": fid / fps if fps > 0 else 0, "embedding": v.tolist()})
-        canonical = [embs[0], embs[len(embs) // 2], embs[-1]] if embs else []
-        return {"embeddings": embs, "canonical_frames": canonical, "total_frames": total, "fps": fps}
+        return self.embeddings_result(embs, total, fps)
 
     def search_similar(self, query, top_k=5):
         try:
@@ -55,34 +58,38 @@ class DINOv3Pipeline:
             print(f"Processed video not found: {processed_path}")
             return
         try:
-            data = self.extract_video_embeddings(processed_path)
-            if not data["embeddings"]:
-                print(f"No embeddings extracted for {video_id}")
-                return
-            avg = np.mean([np.array(e["embedding"]) for e in data["embeddings"]], axis=0)  # float64 (Appendix C-9)
-            similar = self.search_similar(avg, top_k=5)
-            evidence = 0.5
-            if similar:
-                labels = [c["label"] for c in similar if c["label"] is not None]
-                if labels:
-                    evidence = sum(1 for lab in labels if lab == 1) / len(labels)
-            try:
-                self.store.upsert(video_id, avg.tolist(), {"video_id": video_id, "filename": video_data.get("filename", ""),
-                                                           "uploaded_at": video_data.get("uploaded_at", ""), "label": None,
-                                                           "metadata": video_data.get("metadata", {})})
-            except Exception as e:  # noqa: BLE001
-                print(f"Error storing in VectorDB: {e}")
-            results = {"video_id": video_id, "embedding_dim": len(avg), "num_embeddings": len(data["embeddings"]),
-                       "similar_cases": similar, "neighbor_evidence": evidence, "canonical_frames": data["canonical_frames"]}
-            results_file = self.results_dir / f"{video_id}_dinov3.json"
-            with open(results_file, "w") as f:
-                json.dump(results, f, indent=2)
-            await self.nats_client.publish(self.config["nats"]["subjects"]["pipeline_dinov3"], {
-                "video_id": video_id, "pipeline": "dinov3", "results_path": str(results_file), "neighbor_evidence": evidence,
-                "similar_cases": similar, "embedding_dim": len(avg)})
+            await self.finish(video_data, self.extract_video_embeddings(processed_path))
         except Exception as e:  # noqa: BLE001
             print(f"Error in DINOv3 pipeline for {video_id}: {e}")
             traceback.print_exc()
+
+    async def finish(self, video_data, data):
+        """main.py:197-275 after the embeddings exist: float64 clip mean, top-5 search, neighbor_evidence, upsert, file, publish."""
+        video_id = video_data["video_id"]
+        if not data["embeddings"]:
+            print(f"No embeddings extracted for {video_id}")
+            return
+        avg = np.mean([np.array(e["embedding"]) for e in data["embeddings"]], axis=0)  # float64 (Appendix C-9)
+        similar = self.search_similar(avg, top_k=5)
+        evidence = 0.5
+        if similar:
+            labels = [c["label"] for c in similar if c["label"] is not None]
+            if labels:
+                evidence = sum(1 for lab in labels if lab == 1) / len(labels)
+        try:
+            self.store.upsert(video_id, avg.tolist(), {"video_id": video_id, "filename": video_data.get("filename", ""),
+                                                       "uploaded_at": video_data.get("uploaded_at", ""), "label": None,
+                                                       "metadata": video_data.get("metadata", {})})
+        except Exception as e:  # noqa: BLE001
+            print(f"Error storing in VectorDB: {e}")
+        results = {"video_id": video_id, "embedding_dim": len(avg), "num_embeddings": len(data["embeddings"]),
+                   "similar_cases": similar, "neighbor_evidence": evidence, "canonical_frames": data["canonical_frames"]}
+        results_file = self.results_dir / f"{video_id}_dinov3.json"
+        with open(results_file, "w") as f:
+            json.dump(results, f, indent=2)
+        await self.nats_client.publish(self.config["nats"]["subjects"]["pipeline_dinov3"], {
+            "video_id": video_id, "pipeline": "dinov3", "results_path": str(results_file), "neighbor_evidence": evidence,
+            "similar_cases": similar, "embedding_dim": len(avg)})
 
     async def start(self):
         await self.nats_client.connect()

@@ -102,31 +102,28 @@ class NATSClient:
 
 class Clip:
     """What the services take from cv2.VideoCapture: int(fps), int(frame count) and the decoded BGR frames in order
-    (services/yolo-pipeline/app/main.py:55-71).  Sources: a video file via cv2 when it is installed, or an .npz written
-    by ``save_npz_clip`` (frames uint8 [n,h,w,3] BGR, fps float) — the offline stand-in for decoded video."""
+    (services/yolo-pipeline/app/main.py:55-71) — as a STREAM: like the reference's `cap.read()` loop the reader holds one
+    decoded frame at a time and keeps only the frames a caller samples, so a long clip costs memory for the sampled frames
+    only (a 5-minute 1080p clip is 56 GB decoded, 1.1 GB at the services' sampling).  Sources: a video file via cv2 when it
+    is installed, or an .npz written by ``save_npz_clip`` (frames uint8 [n,h,w,3] BGR, fps float) — the offline stand-in
+    for decoded video."""
 
-    def __init__(self, frames, fps):
-        self.frames = frames
-        self.fps = int(fps)  # the reference truncates: int(cap.get(CAP_PROP_FPS)) (Appendix C-1)
-        self.total_frames = int(len(frames))
-
-    _last = (None, None)  # (key, clip): the fused service opens the same clip three times in a row
+    def __init__(self, path=None, frames=None, fps=None):
+        self.path = str(path) if path is not None else None
+        self._frames = frames          # in-memory source (npz stand-in or a caller's array)
+        self.n_decoded = None          # known once a pass over the clip has finished
+        if frames is not None:
+            self.fps = int(fps)        # the reference truncates: int(cap.get(CAP_PROP_FPS)) (Appendix C-1)
+            self.total_frames = int(len(frames))
+            self.n_decoded = self.total_frames
+            self.frame_hw = tuple(frames.shape[1:3]) if len(frames) else (0, 0)
 
     @staticmethod
     def open(path):
         path = str(path)
-        key = (path, os.path.getmtime(path) if os.path.exists(path) else None)
-        if Clip._last[0] == key:
-            return Clip._last[1]
-        c = Clip._open(path)
-        Clip._last = (key, c)
-        return c
-
-    @staticmethod
-    def _open(path):
         if path.endswith(".npz"):
             z = np.load(path)
-            return Clip(z["frames"], float(z["fps"]))
+            return Clip(path, z["frames"], float(z["fps"]))
         try:
             import cv2
         except ImportError as e:
@@ -134,18 +131,52 @@ class Clip:
         cap = cv2.VideoCapture(path)
         if not cap.isOpened():
             raise Exception(f"Failed to open video: {path}")
-        fps = cap.get(cv2.CAP_PROP_FPS)
-        frames = []
-        while True:
-            ok, f = cap.read()
-            if not ok:
-                break
-            frames.append(f)
-        total = int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
+        c = Clip(path)
+        c.fps = int(cap.get(cv2.CAP_PROP_FPS))
+        c.total_frames = int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
+        c.frame_hw = (int(cap.get(cv2.CAP_PROP_FRAME_HEIGHT)), int(cap.get(cv2.CAP_PROP_FRAME_WIDTH)))
         cap.release()
-        c = Clip(np.stack(frames, 0) if frames else np.zeros((0, 0, 0, 3), np.uint8), fps)
-        c.total_frames = total
         return c
+
+    def iter_frames(self, keep=None):
+        """Yield (index, BGR frame) in decode order for the indices `keep(index)` accepts (default: all).  One pass over the
+        file; frames that are not kept are decoded (a codec has to) and dropped at once."""
+        if self._frames is not None:
+            for i in range(len(self._frames)):
+                if keep is None or keep(i):
+                    yield i, self._frames[i]
+            return
+        import cv2
+
+        cap = cv2.VideoCapture(self.path)
+        if not cap.isOpened():
+            raise Exception(f"Failed to open video: {self.path}")
+        i = 0
+        try:
+            while True:
+                ok, f = cap.read()
+                if not ok:
+                    break
+                if keep is None or keep(i):
+                    yield i, f
+                i += 1
+        finally:
+            cap.release()
+        self.n_decoded = i
+
+    def batches(self, intervals, batch):
+        """Yield (indices, frames uint8 [k,h,w,3]) of at most `batch` frames whose index is a multiple of ANY of `intervals`
+        — the union of the services' schedules (`frame_count % frame_interval == 0`, yolo main.py:74, dinov3 main.py:127)."""
+        ivs = tuple(int(v) for v in (intervals if isinstance(intervals, (tuple, list)) else (intervals,)))
+        ids, buf = [], []
+        for i, f in self.iter_frames(lambda k: any(k % iv == 0 for iv in ivs)):
+            ids.append(i)
+            buf.append(f)
+            if len(ids) == batch:
+                yield ids, np.stack(buf, 0)
+                ids, buf = [], []
+        if ids:
+            yield ids, np.stack(buf, 0)
 
 
 def save_npz_clip(path, frames, fps):
@@ -155,6 +186,42 @@ def save_npz_clip(path, frames, fps):
 def sampled(n_decoded, interval):
     """Indices the reference's `frame_count % frame_interval == 0` loop visits."""
     return list(range(0, n_decoded, interval))
+
+
+class PinnedRing:
+    """Pinned-host staging ring for the upload of decoded frames: chunk i+1 is copied to the device on a copy stream while
+    chunk i computes (tools/pcie_probe.py measured 554 frames/s with the overlap vs 520 with blocking
+    uploads).  `upload(frames_numpy)` returns a device tensor that is valid on the CURRENT stream once it has waited on the
+    returned event; a slot is reused only after the event of its previous upload has completed."""
+
+    def __init__(self, device, slots=3):
+        import torch
+
+        self.device = torch.device(device)
+        self.slots = [None] * slots
+        self.events = [None] * slots
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.k = 0
+
+    def upload(self, frames):
+        import torch
+
+        j = self.k % len(self.slots)
+        self.k += 1
+        nbytes = frames.nbytes
+        if self.events[j] is not None:
+            self.events[j].synchronize()  # the copy out of this slot has finished
+        if self.slots[j] is None or self.slots[j].numel() < nbytes:
+            self.slots[j] = torch.empty((nbytes,), dtype=torch.uint8).pin_memory()
+        host = self.slots[j][:nbytes].view(frames.shape)
+        host.numpy()[...] = frames
+        with torch.cuda.stream(self.copy_stream):
+            dev = host.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.events[j] = ev
+        dev.record_stream(torch.cuda.current_stream(self.device))
+        return dev, ev
 
 
 class MemoryVectorStore:

@@ -62,25 +62,61 @@ class SAM3Pipeline:
             return res
         return {}
 
-    def _masks(self, clip, fids, boxes):
-        """-> list of host bool masks for the frames that have a box."""
-        h, w = clip.frames.shape[1:3]
+    def _masks(self, frames_host, boxes):
+        """frames_host uint8 [k,h,w,3] + their boxes -> list of host bool masks."""
+        h, w = frames_host.shape[1:3]
         if self.sam_predictor is None:
             return [fallback_segmentation((h, w), b) for b in boxes]
-        out = []
-        dev = self.sam_predictor.device
-        for i in range(0, len(fids), self.batch):
-            ids, bx = fids[i:i + self.batch], boxes[i:i + self.batch]
-            try:
-                frames = torch.from_numpy(np.ascontiguousarray(clip.frames[ids])).to(dev)
-                m = self.sam_predictor.segment(frames, torch.tensor(bx, dtype=torch.float32, device=dev))
-                # 8x less D2H: the device packs the mask (numpy.packbits order), the host unpacks it
-                bits = K.pack_bits(m).cpu().numpy()
-                out += [a.astype(bool) for a in np.unpackbits(bits, axis=-1, count=m.shape[-1])]
-            except Exception as e:  # noqa: BLE001
-                print(f"SAM3 segmentation error: {e}")
-                out += [fallback_segmentation((h, w), b) for b in bx]
-        return out
+        try:
+            dev = self.sam_predictor.device
+            m = self.sam_predictor.segment(torch.from_numpy(frames_host).to(dev), torch.tensor(boxes, dtype=torch.float32, device=dev))
+            # 8x less D2H: the device packs the mask (numpy.packbits order), the host unpacks it
+            bits = K.pack_bits(m).cpu().numpy()
+            return [a.astype(bool) for a in np.unpackbits(bits, axis=-1, count=m.shape[-1])]
+        except Exception as e:  # noqa: BLE001 — main.py:90-92: a failing segmenter falls back to the rectangle
+            print(f"SAM3 segmentation error: {e}")
+            return [fallback_segmentation((h, w), b) for b in boxes]
+
+    @staticmethod
+    def first_boxes(yolo_results):
+        """{frame: bbox of the FIRST detection} (main.py:199-206; first = highest confidence, Appendix C-3)."""
+        by_frame = {}
+        if yolo_results and "detections" in yolo_results:
+            for det in yolo_results["detections"]:
+                if det["frame"] not in by_frame and det["detections"]:
+                    by_frame[det["frame"]] = det["detections"][0]["bbox"]
+        return by_frame
+
+    @staticmethod
+    def results_from_features(ids, fps, total, feats_by_frame):
+        """main.py:208-254: per sampled frame a segmentation entry, the four means over the frames that have a mask."""
+        segmentations, frame_features = [], []
+        for i in ids:
+            t = i / fps if fps > 0 else 0
+            if i in feats_by_frame:
+                feats = dict(feats_by_frame[i])
+                feats["frame"] = i
+                feats["time"] = t
+                frame_features.append(feats)
+                segmentations.append({"frame": i, "time": t, "mask_available": True, "features": feats})
+            else:
+                segmentations.append({"frame": i, "time": t, "mask_available": False})
+        avg = {}
+        if frame_features:
+            avg = {"avg_mask_area": float(np.mean([f["mask_area"] for f in frame_features])),
+                   "avg_area_ratio": float(np.mean([f["area_ratio"] for f in frame_features])),
+                   "avg_circularity": float(np.mean([f["circularity"] for f in frame_features])),
+                   "avg_aspect_ratio": float(np.mean([f["aspect_ratio"] for f in frame_features]))}
+        return {"segmentations": segmentations, "aggregated_features": avg, "total_frames": total, "fps": fps,
+                "frames_processed": len(segmentations)}
+
+    async def write_and_publish(self, video_id, results):
+        results_file = self.results_dir / f"{video_id}_sam3.json"
+        with open(results_file, "w") as f:
+            json.dump(results, f, indent=2)
+        await self.nats_client.publish(self.config["nats"]["subjects"]["pipeline_sam3"], {
+            "video_id": video_id, "pipeline": "sam3", "results_path": str(results_file), "features": results["aggregated_features"],
+            "num_segmentations": len(results["segmentations"])})
 
     async def process_video(self, video_data):
         video_id = video_data["video_id"]
@@ -89,42 +125,29 @@ class SAM3Pipeline:
             print(f"Processed video not found: {processed_path}")
             return
         try:
-            yolo_results = await self.get_yolo_results(video_id)
+            by_frame = self.first_boxes(await self.get_yolo_results(video_id))
             clip = R.Clip.open(processed_path)
             fps, total = clip.fps, clip.total_frames
-            ids = R.sampled(len(clip.frames), max(1, fps // 2))
-            by_frame = {}
-            if yolo_results and "detections" in yolo_results:
-                for det in yolo_results["detections"]:
-                    if det["frame"] not in by_frame and det["detections"]:
-                        by_frame[det["frame"]] = det["detections"][0]["bbox"]  # first = highest confidence (Appendix C-3)
-            with_box = [i for i in ids if by_frame.get(i)]
-            masks = dict(zip(with_box, self._masks(clip, with_box, [by_frame[i] for i in with_box])))
-            segmentations, frame_features = [], []
-            for i in ids:
-                t = i / fps if fps > 0 else 0
-                if i in masks:
-                    feats = extract_segmentation_features(masks[i])
-                    feats["frame"] = i
-                    feats["time"] = t
-                    frame_features.append(feats)
-                    segmentations.append({"frame": i, "time": t, "mask_available": True, "features": feats})
-                else:
-                    segmentations.append({"frame": i, "time": t, "mask_available": False})
-            avg = {}
-            if frame_features:
-                avg = {"avg_mask_area": float(np.mean([f["mask_area"] for f in frame_features])),
-                       "avg_area_ratio": float(np.mean([f["area_ratio"] for f in frame_features])),
-                       "avg_circularity": float(np.mean([f["circularity"] for f in frame_features])),
-                       "avg_aspect_ratio": float(np.mean([f["aspect_ratio"] for f in frame_features]))}
-            results = {"segmentations": segmentations, "aggregated_features": avg, "total_frames": total, "fps": fps,
-                       "frames_processed": len(segmentations)}
-            results_file = self.results_dir / f"{video_id}_sam3.json"
-            with open(results_file, "w") as f:
-                json.dump(results, f, indent=2)
-            await self.nats_client.publish(self.config["nats"]["subjects"]["pipeline_sam3"], {
-                "video_id": video_id, "pipeline": "sam3", "results_path": str(results_file), "features": avg,
-                "num_segmentations": len(segmentations)})
+            interval = max(1, fps // 2)
+            ids, feats = [], {}
+            pend_ids, pend_frames = [], []
+
+            def flush():
+                if pend_ids:
+                    for i, m in zip(pend_ids, self._masks(np.stack(pend_frames, 0), [by_frame[i] for i in pend_ids])):
+                        feats[i] = extract_segmentation_features(m)
+                    pend_ids.clear()
+                    pend_frames.clear()
+
+            for i, frame in clip.iter_frames(lambda k: k % interval == 0):  # one pass; only frames with a box are kept
+                ids.append(i)
+                if by_frame.get(i):
+                    pend_ids.append(i)
+                    pend_frames.append(frame)
+                    if len(pend_ids) == self.batch:
+                        flush()
+            flush()
+            await self.write_and_publish(video_id, self.results_from_features(ids, fps, total, feats))
         except Exception as e:  # noqa: BLE001
             print(f"Error in SAM3 pipeline for {video_id}: {e}")
             traceback.print_exc()

@@ -63,19 +63,31 @@ class YOLOPipeline:
         self.results_dir.mkdir(parents=True, exist_ok=True)
         self.batch = batch
 
+    def results_from_detections(self, dets, total, fps):
+        """The dict detect_in_video returns (main.py:109-118), from the per-frame detection dicts."""
+        return {"detections": dets, "features": compute_features(dets, total, fps), "total_frames": total, "fps": fps,
+                "frames_processed": len(dets)}
+
     def detect_in_video(self, video_path):
         clip = R.Clip.open(video_path)
         fps, total = clip.fps, clip.total_frames
-        ids = R.sampled(len(clip.frames), max(1, fps // 2))
         dets = []
         dev = self.yolo_model.device
-        for i in range(0, len(ids), self.batch):
-            chunk = ids[i:i + self.batch]
-            frames = torch.from_numpy(np.ascontiguousarray(clip.frames[chunk])).to(dev)
+        # the decode loop of main.py:63-107 as a stream: only the sampled frames are kept, `batch` at a time
+        for chunk, host in clip.batches(max(1, fps // 2), self.batch):
+            frames = torch.from_numpy(host).to(dev)
             b, s, c, _, n = self.yolo_model.detect(frames, conf=self.confidence_threshold)
             dets += detections_from_device(chunk, fps, self.yolo_model.names, b, s, c, n)
-        return {"detections": dets, "features": compute_features(dets, total, fps), "total_frames": total, "fps": fps,
-                "frames_processed": len(dets)}
+        return self.results_from_detections(dets, total, fps)
+
+    async def write_and_publish(self, video_id, results):
+        """main.py:181-199: `{id}_yolo.json` (indent 2) and the `pipeline.yolo` message."""
+        results_file = self.results_dir / f"{video_id}_yolo.json"
+        with open(results_file, "w") as f:
+            json.dump(results, f, indent=2)
+        await self.nats_client.publish(self.config["nats"]["subjects"]["pipeline_yolo"], {
+            "video_id": video_id, "pipeline": "yolo", "results_path": str(results_file), "features": results["features"],
+            "num_detections": len(results["detections"]), "total_frames": results["total_frames"]})
 
     async def process_video(self, video_data):
         video_id = video_data["video_id"]
@@ -84,13 +96,7 @@ class YOLOPipeline:
             print(f"Processed video not found: {processed_path}")
             return
         try:
-            results = self.detect_in_video(processed_path)
-            results_file = self.results_dir / f"{video_id}_yolo.json"
-            with open(results_file, "w") as f:
-                json.dump(results, f, indent=2)
-            await self.nats_client.publish(self.config["nats"]["subjects"]["pipeline_yolo"], {
-                "video_id": video_id, "pipeline": "yolo", "results_path": str(results_file), "features": results["features"],
-                "num_detections": len(results["detections"]), "total_frames": results["total_frames"]})
+            await self.write_and_publish(video_id, self.detect_in_video(processed_path))
         except Exception as e:  # noqa: BLE001 — the reference never raises out of the handler (main.py:203-206)
             print(f"Error in YOLO pipeline for {video_id}: {e}")
             traceback.print_exc()

@@ -29,3 +29,15 @@ def synth_frame(seed, idx, h=1080, w=1920):
 
 def synth_clip(seed, n_frames=150, h=1080, w=1920, start=0):
     return np.stack([synth_frame(seed, start + i, h, w) for i in range(n_frames)], 0)
+
+
+def cfg2_frames(n=32, seed=1, size=640):
+    """BASELINE cfg#2 input: uniform u8 noise + 8 pasted solid rectangles per image, BGR u8 [n,640,640,3]."""
+    rng = np.random.default_rng(seed)
+    fr = rng.integers(0, 256, (n, size, size, 3), dtype=np.uint8)
+    for i in range(n):
+        for _ in range(8):
+            x0, y0 = (int(v) for v in rng.integers(0, size - 64, 2))
+            w, h = (int(v) for v in rng.integers(48, 320, 2))
+            fr[i, y0:min(size, y0 + h), x0:min(size, x0 + w)] = rng.integers(0, 256, 3, dtype=np.uint8)
+    return fr
