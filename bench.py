@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — frames/sec of the fused YOLO + SAM(Hiera-B+) + DINOv3 feature-extraction path on synthetic 1080p clips
-(BASELINE.json metric).  One process per GPU; a step = one pass of the hot path over one batch of `--frames` 1080p
-frames already resident in HBM (dense schedule: every frame through all three networks).
+(BASELINE.json metric, cfg#5).  One process per GPU; a step = one pass of the hot path over ONE synthetic 5 s @ 30 fps
+1080p clip (150 unique frames) already resident in HBM, including the pack of the per-frame records
+(boxes, scores, classes, bit-packed mask + statistics, embedding), the one gather to rank 0 when there are several ranks,
+and their copy to pinned host memory — what the services persist.
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the dominant kernel = the MFMA GEMM,
-timed live with HIP events on the launch stream) and `cpu_baseline` (the fp32 oracle on the host cores, bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is the DENSE schedule (every frame through all
+three networks: the throughput mode); `reference_schedule` reports the services' own schedule (YOLO + SAM on frames
+0, 15, ..., 135, DINO on 0, 30, ..., 120: yolo main.py:67, dinov3 main.py:127) on the same clip.  `roofline` is the kernel class
+with the largest share of GPU time, `roofline_classes` lists every class — each timed live with HIP events on the launch
+stream during K more serialized steps, bound chosen by arithmetic intensity; `cpu_baseline` is the fp32 oracle on the host.
 """
 import argparse
 import json
@@ -22,8 +27,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0     # HBM3E peak, same table (6.3 TB/s is what a streaming copy achieves)
 # algorithmic FLOPs per 1080p frame (SURVEY.md §8d cfg#5): YOLOv8-l @384x640 + Hiera-B+ trunk+FPN @1024^2 + DINOv3 ViT-L/16 @224^2
 GFLOP_PER_FRAME = {"yolo": 99.1, "sam": 645.0, "dino": 125.7}
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")  # rocprofv3 --pmc passes of THIS command (tools/pmc.sh)
 
 
 def cpu_baseline(n_frames, clip_seed):
@@ -56,31 +63,72 @@ def cpu_baseline(n_frames, clip_seed):
             print(f"[bench] cpu_baseline frame {j + 1}/{n_frames} ({time.perf_counter() - t0:.1f}s)", file=sys.stderr, flush=True)
             OY.predict("l", 80, ysd, f, conf=0.5)
             fpn, _ = OH.encoder_forward(scfg, ssd, torch.from_numpy(OP.sam_pixel_values(f, 1024))[None])
-            box = np.array([[300.0, 150.0, 1200.0, 900.0]], np.float32)
+            box = np.array([[300.0, 150.0, 1200.0, 900.0]], np.float32)  # a fixed prompt: the decoder's cost does not depend on it
             sp = OD.prompt_encode_box(msd, torch.from_numpy(OD.scale_box(box, f.shape[:2], (576, 1024))))
             low, _ = OD.mask_decode(msd, fpn[2], sp)
             OD.postprocess(low, (576, 1024), f.shape[:2])
             OV.embed(dcfg, dsd, torch.from_numpy(OP.dino_pixel_values(f))[None])
     dt = time.perf_counter() - t0
     return {"value": n_frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_frames} synthetic 1080p frames, YOLOv8-l + Hiera-B+ encoder + SAM mask decoder + DINOv3 ViT-L/16, fp32 PyTorch CPU, batch 1"}
+            "sample": f"the first {n_frames} frames of the benched clip, dense schedule: YOLOv8-l + Hiera-B+ encoder + SAM mask decoder + DINOv3 ViT-L/16, fp32 PyTorch CPU, batch 1"}
 
 
-def pmc_gemm_traffic():
-    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes of this same command (tools/pmc.sh ->
-    tools/pmc_summary.py -> profiles/r01_pmc_summary.json; FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE),
-    launch-weighted over the GEMM kernels.  Counters cannot be read inside the timed run, so this is the profiled figure."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
+def pmc_traffic_by_class():
+    """HBM bytes per launch and kernel class from the committed rocprofv3 --pmc passes of this same command
+    (tools/pmc.sh -> tools/pmc_summary.py -> profiles/r02_pmc_summary.json; FETCH_SIZE doubled per the gfx950 correction,
+    + WRITE_SIZE).  Counters cannot be read inside the timed run, so this is the profiled figure; None without the file."""
+    if not os.path.exists(PMC_SUMMARY):
+        return {}
+    with open(PMC_SUMMARY) as f:
         rows = json.load(f)
-    n = b = 0.0
+    acc = {}
     for name, r in rows.items():
-        if "gemm2_kernel" in name or "gemm_kernel" in name:
-            n += r["launches"]
-            b += r["launches"] * (r["read_MB"] + r["write_MB"]) * 1e6
-    return b / n if n else None
+        if "gemm2_kernel<1" in name or "gemm_kernel" in name and ", 1>" in name:
+            cls = "gemm/hbm-bound"      # f32-output (residual-stream) instantiations
+        elif "gemm" in name:
+            cls = "gemm/mfma-bound"
+        elif "attn" in name:
+            cls = "attention"
+        elif "ln_mlp" in name:
+            cls = "fused ln+mlp"
+        elif "layernorm" in name:
+            cls = "layernorm"
+        else:
+            continue
+        a = acc.setdefault(cls, [0.0, 0.0])
+        a[0] += r["launches"]
+        a[1] += r["launches"] * (r["read_MB"] + r["write_MB"]) * 1e6
+    return {k: (b / n if n else None) for k, (n, b) in acc.items()}
+
+
+def roofline_classes(trace, wall_s):
+    """Per kernel class: governing bound by arithmetic intensity (flop/byte against the MFMA/HBM ridge), achieved rate =
+    algorithmic work / event-timed duration, fraction of the peak, share of the serialized step."""
+    from lmx import kernels as K
+
+    traffic = pmc_traffic_by_class()
+    total = sum(r["seconds"] for r in trace.values()) or 1.0
+    out = []
+    for cls, r in sorted(trace.items(), key=lambda kv: -kv[1]["seconds"]):
+        row = {"kernel": cls, "launches": r["launches"], "time_share": r["seconds"] / total, "avg_us": r["seconds"] / r["launches"] * 1e6}
+        if r["modelled"] and r["bytes"] > 0:
+            ai = r["flops"] / r["bytes"]
+            mfma = ai >= K.RIDGE_FLOP_PER_BYTE
+            if cls == "fused ln+mlp":
+                mfma = True  # 16*D flop per byte at D = 112 / 224: above the ridge only nominally; the MFMA pipe bounds it (DESIGN 3)
+            if mfma:
+                ach = r["flops"] / r["seconds"] / 1e12
+                row.update(bound="mfma", achieved=ach, peak=PEAK_F16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F16_TFLOPS)
+            else:
+                ach = r["bytes"] / r["seconds"] / 1e9
+                row.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS)
+            row["flop_per_launch"] = r["flops"] / r["launches"]
+            row["bytes_per_launch"] = r["bytes"] / r["launches"]
+            row["traffic"] = traffic.get(cls)
+        else:
+            row.update(bound=None, achieved=None, peak=None, unit=None, frac=None, traffic=None)
+        out.append(row)
+    return out, total / wall_s if wall_s > 0 else None
 
 
 def main():
@@ -88,10 +136,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=64, help="1080p frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=150, help="frames of the synthetic clip per GPU per step (5 s @ 30 fps = 150)")
+    ap.add_argument("--fps", type=int, default=30)
     ap.add_argument("--sam-chunk", type=int, default=16, help="frames per SAM encoder pass (each pass runs on its own HIP stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--no-reference-schedule", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=10)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,75 +178,112 @@ def main():
 
     log("building synthetic weights")
     fx = pipeline.FusedExtractor(dev)
-    log("generating synthetic frames")
-    # each rank owns a contiguous block of the synthetic clip (weak scaling: per-GPU work fixed)
-    host = np.stack([synth.synth_frame(100 + rank, i) for i in range(min(args.frames, 8))], 0)
-    host = np.concatenate([host] * (-(-args.frames // host.shape[0])), 0)[:args.frames]
+    log(f"generating the synthetic clip ({args.frames} unique 1080p frames per rank)")
+    # weak scaling: every rank owns one clip (seed = 100 + rank); frames are unique within the clip
+    host = synth.synth_clip(100 + rank, args.frames)
     frames = torch.from_numpy(host).to(dev)
+    del host
+    i_det, i_emb = max(1, args.fps // 2), max(1, args.fps)
+    sched = sorted(set(range(0, args.frames, i_det)) | set(range(0, args.frames, i_emb)))
+    sched_frames = frames[sched].contiguous()
+    det_idx = [j for j, i in enumerate(sched) if i % i_det == 0]
+    emb_idx = [j for j, i in enumerate(sched) if i % i_emb == 0]
+    pinned = {}
 
-    def step():
-        out = fx.step(frames, sam_chunk=args.sam_chunk)
-        return ldist.gather_frame_records(out) if world > 1 else out
+    def persist(out):
+        """What leaves the GPU per clip: ONE packed record buffer -> (one gather to rank 0) -> pinned host memory."""
+        out = {k: v for k, v in out.items() if k != "mask"}
+        buf, _ = ldist.pack_records(out)
+        if world > 1:
+            buf = ldist.gather_packed(buf, root=0)
+            if buf is None:
+                return
+        key = tuple(buf.shape)
+        if key not in pinned:
+            pinned[key] = torch.empty(buf.shape, dtype=torch.uint8).pin_memory()
+        pinned[key].copy_(buf, non_blocking=True)
 
-    for i in range(args.warmup):
-        step()
+    def step_dense():
+        persist(fx.step(frames, sam_chunk=args.sam_chunk))
+
+    def step_reference():
+        persist(fx.step(sched_frames, sam_chunk=args.sam_chunk, det_idx=det_idx, emb_idx=emb_idx))
+
+    def timed(step, label):
+        for i in range(args.warmup):
+            step()
+            torch.cuda.synchronize()
+            log(f"{label}: warmup step {i + 1}/{args.warmup} done")
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        log(f"warmup step {i + 1}/{args.warmup} done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    log(f"timed region: {args.steps} steps in {dt:.3f}s")
-    # Roofline leg: the timed steps keep three HIP streams in flight (YOLO+DINO beside two SAM passes), so an event pair
-    # around one launch would time its neighbours too.  The GEMM launches are therefore bracketed on K more steps of the
-    # SAME workload run on one stream (not part of `value`); rocprofv3's per-kernel averages in profiles/ are taken the
-    # same way (LMX_SERIAL=1).
-    # (every rank replays, without collectives, so that all ranks reach the closing all-reduce together; rank 0 reports)
-    fx.serial = True
-    fx.step(frames, sam_chunk=args.sam_chunk)
-    torch.cuda.synchronize()
-    K.start_gemm_trace()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        log(f"{label}: {args.steps} steps in {dt:.3f}s")
+        return dt
+
+    dt = timed(step_dense, "dense schedule")
+    dt_ref = None if args.no_reference_schedule else timed(step_reference, "reference schedule")
+
+    # Roofline leg: the timed steps keep up to six HIP streams in flight, so an event pair around one launch would time its
+    # neighbours too.  Every launch is therefore bracketed on K more steps of the SAME workload run on one stream (not part
+    # of `value`); rocprofv3's per-kernel averages in profiles/ are taken the same way (LMX_SERIAL=1).
+    # (every rank replays, without collectives; rank 0 reports)
+    classes, traced_share, dt_serial = None, None, None
+    if not args.no_roofline:
+        fx.serial = True
         fx.step(frames, sam_chunk=args.sam_chunk)
-    torch.cuda.synchronize()
-    dt_serial = time.perf_counter() - t1
-    g_flops, g_secs, g_launches = K.stop_gemm_trace()
-    fx.serial = False
-    log(f"roofline pass: {args.steps} serialized steps in {dt_serial:.3f}s")
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        torch.cuda.synchronize()
+        K.start_launch_trace()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fx.step(frames, sam_chunk=args.sam_chunk)
+        torch.cuda.synchronize()
+        dt_serial = time.perf_counter() - t1
+        trace = K.stop_launch_trace()
+        fx.serial = False
+        classes, traced_share = roofline_classes(trace, dt_serial)
+        for c in classes:
+            c["launches_per_step"] = c.pop("launches") // max(args.steps, 1)
+        log(f"roofline pass: {args.steps} serialized steps in {dt_serial:.3f}s")
 
     if rank == 0:
         total_frames = args.frames * world * args.steps
-        achieved = g_flops / g_secs / 1e12 if g_secs > 0 else 0.0
         line = {
             "metric": "frames/sec (whole node) for YOLO+SAM3+DINOv3 feature extraction, 1080p clips",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "fused dense per-frame path: YOLOv8-l detect (letterbox 384x640, NMS, scale_boxes) -> SAM "
-                                   "(Hiera-B+ image encoder + FPN at 1024x1024, box-prompted mask decoder, 1080p mask + stats) "
-                                   "+ DINOv3 ViT-L/16 embed (224x224) on every frame of synthetic 1080p BGR clips resident in "
-                                   "HBM; synthetic weights",
-                       "frames_per_gpu_per_step": args.frames, "parallelism": f"frames sharded over {world} GPU(s)",
-                       "gflop_per_frame": sum(GFLOP_PER_FRAME.values())},
-            "roofline": {"bound": "mfma", "kernel": "gemm2_kernel / gemm_kernel (lmx_k_gemm: every Linear, 1x1 and 3x3-implicit-GEMM launch)",
-                         "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
-                         "traffic": pmc_gemm_traffic(), "launches_per_step": g_launches // max(args.steps, 1),
-                         "flop_per_launch": g_flops / max(g_launches, 1),
-                         "gemm_time_share": g_secs / dt_serial if dt_serial > 0 else None,
-                         "measured_on": "the same steps replayed on one HIP stream after the timed region "
-                                        f"({dt_serial / args.steps * 1e3:.1f} ms/step serialized)"},
+            "config": {"workload": "BASELINE cfg#5, dense schedule: fused per-frame path on one synthetic 5 s @ 30 fps 1080p clip per GPU "
+                                   "and step (150 unique BGR frames resident in HBM): YOLOv8-l detect (letterbox 384x640, NMS, scale_boxes) "
+                                   "-> SAM (Hiera-B+ image encoder + FPN at 1024x1024, box-prompted mask decoder, 1080p mask + statistics) "
+                                   "+ DINOv3 ViT-L/16 embed (224x224) on EVERY frame; per-frame records packed, gathered to rank 0 and "
+                                   "copied to pinned host memory inside the step; synthetic weights",
+                       "frames_per_gpu_per_step": args.frames, "parallelism": f"one clip per GPU, {world} GPU(s), one gather per step",
+                       "gflop_per_frame": sum(GFLOP_PER_FRAME.values()), "streams": fx.max_streams},
         }
+        if dt_ref is not None:
+            line["reference_schedule"] = {
+                "value": total_frames / dt_ref, "unit": "clip frames/s", "ms_per_clip": dt_ref / args.steps * 1e3,
+                "network_passes_per_clip": {"yolo+sam": len(det_idx), "dino": len(emb_idx)},
+                "note": "the services' own sampling (yolo main.py:67, dinov3 main.py:127): YOLO+SAM on frames 0,15,..,135, DINO on 0,30,..,120 "
+                        "of the same clip; the mode whose JSON matches the reference"}
+        if classes:
+            modelled = [c for c in classes if c["bound"]]
+            head = max(modelled, key=lambda c: c["time_share"])
+            line["roofline"] = dict(head, measured_on=f"the same steps replayed on one HIP stream after the timed region "
+                                                      f"({dt_serial / args.steps * 1e3:.1f} ms/step serialized; events cover "
+                                                      f"{100 * traced_share:.0f} % of it)")
+            line["roofline_classes"] = classes
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames, 100)
         print(json.dumps(line), flush=True)

@@ -474,49 +474,89 @@ def mask_post(logits, T, nh, nw, h, w):
     return mask, stats
 
 
-# ---- optional per-launch timing of the GEMM kernel (bench.py's roofline leg) -------------------------------------
-# When GEMM_TRACE is a list, every gemm/conv launch appends (algorithmic_flops, start_event, end_event); the events
-# are recorded on torch's current stream, i.e. the stream the kernel itself is enqueued on.
-GEMM_TRACE = None
-_raw_gemm_call = None
+# ---- optional per-launch timing (bench.py's roofline leg) -----------------------------------------------------------
+# While a trace is active every lmx_k_* entry point is bracketed by a HIP event pair recorded on the stream the launch goes
+# to (torch's current stream of the operands' device), together with the ALGORITHMIC work of the call: flops and the minimal
+# bytes its operands and results occupy (no re-reads, no workspace) - DESIGN.md section 3 states the per-unit figures.
+LAUNCH_TRACE = None
+_raw_lib = None
+RIDGE_FLOP_PER_BYTE = 2500e12 / 8e12  # dense f16 MFMA peak / HBM peak (MI355X_MICROARCH.md): above it a launch is MFMA-bound
+
+
+def _work(name, args):
+    """(class, flops, bytes) of one C-ABI call; bytes None = not modelled (pre/post-processing glue: time share only)."""
+    if name == "lmx_k_gemm":
+        d = args[0]._obj
+        M, N, Kd = d.M, d.N, d.K
+        osz = 4 if d.out_dtype == F32 else 2
+        a_bytes = 2 * M * Kd
+        if d.a_mode == 1:  # 3x3 implicit GEMM: the input image is read once, not 9 times
+            a_bytes = 2 * (M // max(d.Ho * d.Wo, 1)) * d.H * d.W_ * d.Cin
+        by = a_bytes + 2 * N * Kd + osz * M * N + (osz * (d.res_rows or M) * N if d.res else 0)
+        fl = 2.0 * M * N * Kd
+        return ("gemm/mfma-bound" if fl / by >= RIDGE_FLOP_PER_BYTE else "gemm/hbm-bound"), fl, by
+    if name == "lmx_k_attention":
+        d = args[0]._obj
+        fl = 4.0 * d.B * d.H * d.Tq * d.Tk * d.hd
+        by = 2 * d.H * d.hd * d.B * (2 * d.Tq + 2 * d.Tk)
+        return "attention", fl, by
+    if name == "lmx_k_layernorm":
+        in_dt, out_dt, rows, D = args[1], args[6], args[8], args[9]
+        return "layernorm", 0.0, rows * D * ((4 if in_dt == F32 else 2) + (4 if out_dt == F32 else 2))
+    if name == "lmx_k_ln_mlp":
+        rows, D = args[8], args[9]
+        return "fused ln+mlp", 16.0 * D * D * rows, 16 * D * rows
+    return "pre/post-processing and glue", 0.0, None
 
 
 def _install_trace():
-    global _raw_gemm_call
-    if _raw_gemm_call is not None:
+    global _raw_lib
+    if _raw_lib is not None:
         return
-    lib = _lib.load()
-    _raw_gemm_call = lib.lmx_k_gemm
+    lib = _raw_lib = _lib.load()
 
-    def traced(desc_ref, stream):
-        if GEMM_TRACE is None:
-            return _raw_gemm_call(desc_ref, stream)
-        d = desc_ref._obj
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = _raw_gemm_call(desc_ref, stream)
-        e1.record()
-        GEMM_TRACE.append((2.0 * d.M * d.N * d.K, e0, e1))
-        return rc
+    def make(name, fn):
+        def traced(*args):
+            if LAUNCH_TRACE is None:
+                return fn(*args)
+            cls, fl, by = _work(name, args)
+            st = torch.cuda.current_stream(_cur_dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = fn(*args)
+            e1.record(st)
+            LAUNCH_TRACE.append((cls, name, fl, by, e0, e1))
+            return rc
+
+        return traced
 
     class _Proxy:
         def __getattr__(self, name):
-            return traced if name == "lmx_k_gemm" else getattr(lib, name)
+            fn = getattr(lib, name)
+            if name.startswith("lmx_k_"):
+                fn = make(name, fn)
+            setattr(self, name, fn)
+            return fn
 
     _lib._lib = _Proxy()
 
 
-def start_gemm_trace():
-    global GEMM_TRACE
+def start_launch_trace():
+    global LAUNCH_TRACE
     _install_trace()
-    GEMM_TRACE = []
+    LAUNCH_TRACE = []
 
 
-def stop_gemm_trace():
-    """-> (total algorithmic flops, total seconds, launches) over the traced GEMM launches."""
-    global GEMM_TRACE
-    tr, GEMM_TRACE = GEMM_TRACE or [], None
+def stop_launch_trace():
+    """-> {class: dict(launches, seconds, flops, bytes)} over the traced launches (events read after a device sync)."""
+    global LAUNCH_TRACE
+    tr, LAUNCH_TRACE = LAUNCH_TRACE or [], None
     torch.cuda.synchronize()
-    flops = sum(f for f, _, _ in tr)
-    secs = sum(a.elapsed_time(b) for _, a, b in tr) * 1e-3
-    return flops, secs, len(tr)
+    out = {}
+    for cls, name, fl, by, e0, e1 in tr:
+        r = out.setdefault(cls, dict(launches=0, seconds=0.0, flops=0.0, bytes=0.0, modelled=by is not None))
+        r["launches"] += 1
+        r["seconds"] += e0.elapsed_time(e1) * 1e-3
+        r["flops"] += fl
+        r["bytes"] += by or 0.0
+    return out

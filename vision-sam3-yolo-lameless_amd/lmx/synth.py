@@ -12,9 +12,12 @@ def _background(rng, h, w):
     return np.clip(big + fine, 0, 255).astype(np.uint8)
 
 
-def synth_frame(seed, idx, h=1080, w=1920):
-    rng = np.random.default_rng([int(seed), 7919])
-    img = _background(rng, h, w).copy()
+def synth_frame(seed, idx, h=1080, w=1920, background=None):
+    """`background`: the clip's background if the caller already has it (it depends on the seed only; synth_clip reuses it)."""
+    if background is None:
+        rng = np.random.default_rng([int(seed), 7919])
+        background = _background(rng, h, w)
+    img = background.copy()
     # moving textured box ("cow"): ~40% of the height, walks left to right
     bh, bw = int(h * 0.42), int(w * 0.30)
     x0 = int((w - bw) * ((idx % 150) / 149.0))
@@ -28,7 +31,11 @@ def synth_frame(seed, idx, h=1080, w=1920):
 
 
 def synth_clip(seed, n_frames=150, h=1080, w=1920, start=0):
-    return np.stack([synth_frame(seed, start + i, h, w) for i in range(n_frames)], 0)
+    bg = _background(np.random.default_rng([int(seed), 7919]), h, w)
+    out = np.empty((n_frames, h, w, 3), np.uint8)
+    for i in range(n_frames):
+        out[i] = synth_frame(seed, start + i, h, w, background=bg)
+    return out
 
 
 def cfg2_frames(n=32, seed=1, size=640):
