@@ -114,8 +114,6 @@ def roofline_classes(trace, wall_s):
         if r["modelled"] and r["bytes"] > 0:
             ai = r["flops"] / r["bytes"]
             mfma = ai >= K.RIDGE_FLOP_PER_BYTE
-            if cls == "fused ln+mlp":
-                mfma = True  # 16*D flop per byte at D = 112 / 224: above the ridge only nominally; the MFMA pipe bounds it
             if mfma:
                 ach = r["flops"] / r["seconds"] / 1e12
                 row.update(bound="mfma", achieved=ach, peak=PEAK_F16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F16_TFLOPS)
@@ -143,6 +141,7 @@ def main():
     ap.add_argument("--no-reference-schedule", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=10)
+    ap.add_argument("--shapes-out", default=None, help="write the per-shape table of the roofline leg (text) to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -249,7 +248,14 @@ def main():
             fx.step(frames, sam_chunk=args.sam_chunk)
         torch.cuda.synchronize()
         dt_serial = time.perf_counter() - t1
-        trace = K.stop_launch_trace()
+        trace, shapes = K.stop_launch_trace(by_shape=True)
+        if args.shapes_out and rank == 0:
+            with open(args.shapes_out, "w") as f:
+                f.write(f"# per (class, shape): launches/step, avg us, % of traced time, TFLOP/s, GB/s (algorithmic)   [{args.steps} serialized steps of {args.frames} frames]\n")
+                tot = sum(r["seconds"] for r in shapes.values())
+                for (cls, key), r in sorted(shapes.items(), key=lambda kv: -kv[1]["seconds"]):
+                    f.write(f"{100 * r['seconds'] / tot:5.2f}%  {r['launches'] // args.steps:4d}x {r['seconds'] / r['launches'] * 1e6:8.1f} us  "
+                            f"{r['flops'] / r['seconds'] / 1e12:7.1f} TF  {r['bytes'] / r['seconds'] / 1e9:7.0f} GB/s  [{cls}] {key}\n")
         fx.serial = False
         classes, traced_share = roofline_classes(trace, dt_serial)
         for c in classes:

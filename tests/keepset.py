@@ -105,19 +105,32 @@ def classify(ref, conf, iou_thr, eps_s, eps_i, max_det=300):
             state[i] = KEEP
     firm = set(order[state == KEEP].tolist())
     amb = set(order[state == AMB].tolist())
-    if len(firm) + len(amb) > max_det:
-        # the max_det cut makes everything behind it depend on what was kept before it: treat the tail as ambiguous
-        kept_sorted = [a for a in order.tolist() if a in firm or a in amb]
-        tail = set(kept_sorted[max_det - len(amb):]) if len(amb) < max_det else set(kept_sorted)
-        amb |= firm & tail
-        firm -= tail
+    # the max_det cut (non_max_suppression keeps the first max_det survivors in score order): a survivor is firmly kept when
+    # fewer than max_det survivors (firm or ambiguous) can precede it on the device (score > its score - 2 eps), firmly cut
+    # when max_det FIRM survivors surely precede it (score > its score + 2 eps), ambiguous otherwise
+    surv = [(a, float(score[a])) for a in order.tolist() if a in firm or a in amb]
+    if len(surv) > max_det:
+        sc_any = np.asarray([v for _, v in surv])
+        sc_firm = np.asarray([v for a, v in surv if a in firm])
+        for pos, (a, v) in enumerate(surv):
+            if eps_s == 0:
+                may_precede, surely_precede = pos, sum(1 for b, _ in surv[:pos] if b in firm)
+            else:
+                may_precede = int((sc_any > v - 2 * eps_s).sum()) - 1
+                surely_precede = int((sc_firm > v + 2 * eps_s).sum())
+            if surely_precede >= max_det:
+                firm.discard(a)
+                amb.discard(a)
+            elif may_precede >= max_det and a in firm:
+                firm.discard(a)
+                amb.add(a)
     return firm, amb, {int(a): int(c) for a, c in zip(order, cls)}
 
 
-def check_keepset(ref, conf, iou_thr, eps_s, eps_i, dev_src, dev_cls, label=""):
+def check_keepset(ref, conf, iou_thr, eps_s, eps_i, dev_src, dev_cls, label="", max_det=300):
     """Raises AssertionError unless FIRM <= device keep-set <= FIRM | AMBIGUOUS with equal classes on FIRM.
     -> dict(n_firm, n_ambiguous, n_dev, n_dev_ambiguous) for the report."""
-    firm, amb, cls_of = classify(ref, conf, iou_thr, eps_s, eps_i)
+    firm, amb, cls_of = classify(ref, conf, iou_thr, eps_s, eps_i, max_det)
     dev = [int(a) for a in np.asarray(dev_src).tolist()]
     dset = set(dev)
     assert len(dset) == len(dev), f"{label}: duplicate anchors in the device keep-set"

@@ -133,7 +133,9 @@ def test_yolo_end_to_end(cuda, scale, frames):
             assert eps_s <= EPS_SCORE_CAP and eps_i <= EPS_IOU_CAP, f"frame {j} conf {conf}: f16 deviation eps_score {eps_s} eps_iou {eps_i}"
             rep = KS.check_keepset(cref, conf, 0.7, eps_s, eps_i, rsrc, rc, f"yolov8{scale} frame {j} conf {conf}")
             report.append((j, conf, rep["n_dev"], len(g_src), rep["n_firm"], rep["n_ambiguous"], float(eps_s), float(eps_i)))
-            assert rep["n_firm"] >= 0.5 * len(g_src) or len(g_src) < 4, f"margin too wide to mean anything: {rep} vs {len(g_src)} fp32 detections"
+            # the margin must leave the rule something to check (at conf 0.25 these synthetic weights give 500+ NMS survivors,
+            # so the max_det = 300 cut adds rank ambiguity on top: the floor there is lower)
+            assert rep["n_firm"] >= (0.5 if len(g_src) < 300 else 0.25) * len(g_src) or len(g_src) < 4, f"margin too wide to mean anything: {rep} vs {len(g_src)} fp32 detections"
             if len(g_src) and k:
                 # the detection SAM is prompted with (first = highest confidence) must be the same anchor unless
                 # the fp32 top-2 scores are within 2 * eps_score of each other
@@ -281,7 +283,7 @@ def test_cfg2_yolov8l_640x640_batch32(cuda):
             rep = KS.check_keepset(cref, conf, 0.7, eps_s, eps_i, src[fi, :k], c[fi, :k], f"cfg2 frame {fi} conf {conf}")
             n_gold = len(g[f"f{j}_c{int(conf * 100)}_src"])
             report.append((int(fi), conf, k, n_gold, rep["n_firm"], rep["n_ambiguous"], float(eps_s), float(eps_i)))
-            assert rep["n_firm"] >= 0.5 * n_gold
+            assert rep["n_firm"] >= (0.5 if n_gold < 300 else 0.25) * n_gold, f"margin too wide to mean anything: {rep} vs {n_gold}"
     print("cfg2 (frame, conf, kept_gpu, kept_fp32, firm, ambiguous, eps_score, eps_iou):", report)
     # bit-reproducible, and batch-independent
     pred2 = det.forward_letterboxed(img)

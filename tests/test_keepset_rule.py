@@ -23,8 +23,9 @@ def _random_pred(rng, n_clusters=12, per=14, nc=3):
     return np.asarray(rows, np.float32)
 
 
+@pytest.mark.parametrize("max_det", [300, 12])
 @pytest.mark.parametrize("seed", range(12))
-def test_bounded_perturbations_pass(seed):
+def test_bounded_perturbations_pass(seed, max_det):
     rng = np.random.default_rng(seed)
     pred = _random_pred(rng)
     ref = KS.compact_pred(pred)
@@ -35,8 +36,8 @@ def test_bounded_perturbations_pass(seed):
         dev = KS.compact_pred(d)
         for conf in (0.25, 0.5):
             eps_s, eps_i, _ = KS.measure_eps(ref, dev, conf, window=1.0, iou_floor=0.0)
-            _, _, cls, src = ONMS.non_max_suppression(d, conf)
-            rep = KS.check_keepset(ref, conf, 0.7, eps_s, eps_i, src, cls, f"seed {seed} trial {trial} conf {conf}")
+            _, _, cls, src = ONMS.non_max_suppression(d, conf, max_det=max_det)
+            rep = KS.check_keepset(ref, conf, 0.7, eps_s, eps_i, src, cls, f"seed {seed} trial {trial} conf {conf}", max_det=max_det)
             assert rep["n_firm"] + rep["n_ambiguous"] >= rep["n_dev"]
 
 
@@ -70,3 +71,20 @@ def test_small_eps_still_catches_a_firm_miss():
     keep = src != victim
     with pytest.raises(AssertionError):
         KS.check_keepset(ref, 0.5, 0.7, 5e-3, 1e-2, src[keep], cls[keep])
+
+
+def test_max_det_cut():
+    """More survivors than max_det: with eps = 0 the rule equals the truncated oracle NMS; with eps > 0 only survivors whose
+    rank can straddle the cut become ambiguous."""
+    rng = np.random.default_rng(5)
+    n = 60
+    pred = np.zeros((n, 4 + 2), np.float32)
+    pred[:, 0] = 50 + 100 * np.arange(n)  # far apart: nothing suppresses anything
+    pred[:, 1], pred[:, 2], pred[:, 3] = 50, 40, 40
+    pred[:, 4] = np.linspace(0.9, 0.3, n).astype(np.float32)
+    ref = KS.compact_pred(pred)
+    firm, amb, _ = KS.classify(ref, 0.25, 0.7, 0.0, 0.0, max_det=20)
+    _, _, cls, src = ONMS.non_max_suppression(pred, 0.25, max_det=20)
+    assert firm == set(src.tolist()) and not amb
+    firm, amb, _ = KS.classify(ref, 0.25, 0.7, 0.011, 0.0, max_det=20)  # score step is ~0.0102: ranks can move by two places
+    assert set(range(0, 16)) <= firm and firm <= set(range(0, 20)) and amb and max(amb) <= 24 and min(amb) >= 16

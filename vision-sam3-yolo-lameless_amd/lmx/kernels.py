@@ -494,19 +494,21 @@ def _work(name, args):
             a_bytes = 2 * (M // max(d.Ho * d.Wo, 1)) * d.H * d.W_ * d.Cin
         by = a_bytes + 2 * N * Kd + osz * M * N + (osz * (d.res_rows or M) * N if d.res else 0)
         fl = 2.0 * M * N * Kd
-        return ("gemm/mfma-bound" if fl / by >= RIDGE_FLOP_PER_BYTE else "gemm/hbm-bound"), fl, by
+        key = f"gemm M={M} N={N} K={Kd} out={'f32' if osz == 4 else 'f16'} conv3x3={d.a_mode} act={d.act} res={int(bool(d.res))}"
+        return ("gemm/mfma-bound" if fl / by >= RIDGE_FLOP_PER_BYTE else "gemm/hbm-bound"), fl, by, key
     if name == "lmx_k_attention":
         d = args[0]._obj
         fl = 4.0 * d.B * d.H * d.Tq * d.Tk * d.hd
         by = 2 * d.H * d.hd * d.B * (2 * d.Tq + 2 * d.Tk)
-        return "attention", fl, by
+        key = f"attention B={d.B} H={d.H} Tq={d.Tq} Tk={d.Tk} hd={d.hd} mode={d.mode} ws={d.ws} qs={d.q_stride} rel={int(bool(d.rel))}"
+        return ("attention/mfma-bound" if fl / by >= RIDGE_FLOP_PER_BYTE else "attention/hbm-bound"), fl, by, key
     if name == "lmx_k_layernorm":
         in_dt, out_dt, rows, D = args[1], args[6], args[8], args[9]
-        return "layernorm", 0.0, rows * D * ((4 if in_dt == F32 else 2) + (4 if out_dt == F32 else 2))
+        return "layernorm", 0.0, rows * D * ((4 if in_dt == F32 else 2) + (4 if out_dt == F32 else 2)), f"layernorm rows={rows} D={D} in={in_dt} out={out_dt}"
     if name == "lmx_k_ln_mlp":
         rows, D = args[8], args[9]
-        return "fused ln+mlp", 16.0 * D * D * rows, 16 * D * rows
-    return "pre/post-processing and glue", 0.0, None
+        return "fused ln+mlp", 16.0 * D * D * rows, 16 * D * rows, f"ln_mlp rows={rows} D={D}"
+    return "pre/post-processing and glue", 0.0, None, name
 
 
 def _install_trace():
@@ -519,13 +521,13 @@ def _install_trace():
         def traced(*args):
             if LAUNCH_TRACE is None:
                 return fn(*args)
-            cls, fl, by = _work(name, args)
+            cls, fl, by, key = _work(name, args)
             st = torch.cuda.current_stream(_cur_dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             rc = fn(*args)
             e1.record(st)
-            LAUNCH_TRACE.append((cls, name, fl, by, e0, e1))
+            LAUNCH_TRACE.append((cls, key, fl, by, e0, e1))
             return rc
 
         return traced
@@ -547,16 +549,19 @@ def start_launch_trace():
     LAUNCH_TRACE = []
 
 
-def stop_launch_trace():
-    """-> {class: dict(launches, seconds, flops, bytes)} over the traced launches (events read after a device sync)."""
+def stop_launch_trace(by_shape=False):
+    """-> {class: dict(launches, seconds, flops, bytes)} over the traced launches (events read after a device sync);
+    by_shape=True keys the table by (class, operand shape) instead."""
     global LAUNCH_TRACE
     tr, LAUNCH_TRACE = LAUNCH_TRACE or [], None
     torch.cuda.synchronize()
-    out = {}
-    for cls, name, fl, by, e0, e1 in tr:
-        r = out.setdefault(cls, dict(launches=0, seconds=0.0, flops=0.0, bytes=0.0, modelled=by is not None))
-        r["launches"] += 1
-        r["seconds"] += e0.elapsed_time(e1) * 1e-3
-        r["flops"] += fl
-        r["bytes"] += by or 0.0
-    return out
+    out, shapes = {}, {}
+    for cls, key, fl, by, e0, e1 in tr:
+        dt = e0.elapsed_time(e1) * 1e-3
+        for table, k in ((out, cls), (shapes, (cls, key))):
+            r = table.setdefault(k, dict(launches=0, seconds=0.0, flops=0.0, bytes=0.0, modelled=by is not None))
+            r["launches"] += 1
+            r["seconds"] += dt
+            r["flops"] += fl
+            r["bytes"] += by or 0.0
+    return (out, shapes) if by_shape else out
