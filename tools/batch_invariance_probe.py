@@ -23,6 +23,17 @@ for (rows, N, Kd) in [(240, 256, 128), (240, 512, 1152), (960, 128, 64), (3840, 
         o1 = K.gemm(a1, w, out_dtype=od)
         o3 = K.gemm(a3, w, out_dtype=od)[:rows]
         print(f"gemm rows={rows} N={N} K={Kd} out={od}: {'identical' if torch.equal(o1, o3) else 'DIFFERENT max ' + str(float((o1.float() - o3.float()).abs().max()))}")
+for act in (K.ACT_GELU, K.ACT_SILU):  # bias + activation + LayerScale + f16 / f32 residual: the full epilogue of both kernels
+    for od in (torch.float16, torch.float32):
+        rows, N, Kd = 240, 256, 128
+        a1 = torch.randn(rows, Kd, device=dev, generator=g).half()
+        a3 = torch.cat([a1, torch.randn(2 * rows, Kd, device=dev, generator=g).half()], 0)
+        w = (torch.randn(N, Kd, device=dev, generator=g) * Kd ** -0.5).half()
+        bias, scale = torch.randn(N, device=dev, generator=g), torch.rand(N, device=dev, generator=g) + 0.5
+        r3 = torch.randn(3 * rows, N, device=dev, generator=g).to(od)
+        o1 = K.gemm(a1, w, bias=bias, act=act, scale=scale, res=r3[:rows].contiguous(), out_dtype=od)
+        o3 = K.gemm(a3, w, bias=bias, act=act, scale=scale, res=r3, out_dtype=od)[:rows]
+        print(f"gemm epilogue act={act} out={od}: {'identical' if torch.equal(o1, o3) else 'DIFFERENT max ' + str(float((o1.float() - o3.float()).abs().max()))}")
 for (h, w_, cin, cout) in [(12, 20, 256, 256), (24, 40, 128, 128), (48, 80, 64, 64), (12, 20, 512, 512)]:
     x1 = torch.randn(1, h, w_, cin, device=dev, generator=g).half()
     x3 = torch.cat([x1, torch.randn(2, h, w_, cin, device=dev, generator=g).half()], 0)

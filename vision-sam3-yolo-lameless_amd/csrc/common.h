@@ -75,6 +75,16 @@ __device__ __forceinline__ float gelu_1(float v) {
   return r[0];
 }
 
+// The activation of every GEMM / conv epilogue.  ONE definition for all kernel variants: which variant the launcher picks
+// depends on M = frames x pixels, so two variants that rounded differently would make a frame's result depend on the batch
+// it rides in (tools/batch_invariance_probe.py).  SiLU by v_exp / v_rcp, erf-GELU by the polynomial above.
+__device__ __forceinline__ float lmx_act(float v, int act) {
+  if (act == LMX_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.44269504088896340736f));
+  if (act == LMX_ACT_GELU) return gelu_1(v);
+  if (act == LMX_ACT_RELU) return fmaxf(v, 0.0f);
+  return v;
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // One LDS-DMA wave-instruction (buffer_load_dwordx4 ... lds): lane i's 16 bytes land at dst + 16*i.  Kept in a

@@ -27,14 +27,6 @@ namespace {
 
 constexpr int BK = 64;
 
-template <int ACT>
-__device__ __forceinline__ float apply_act(float v) {
-  if (ACT == LMX_ACT_SILU) return v / (1.0f + expf(-v));
-  if (ACT == LMX_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-  if (ACT == LMX_ACT_RELU) return fmaxf(v, 0.0f);
-  return v;
-}
-
 template <int BM, int BN, int AMODE, int OUT_DT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const lmx_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -189,31 +181,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lmx_gemm_desc p) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
         v += b;
       }
-      switch (p.act) {
-        case LMX_ACT_SILU:
+      // the same rounding sequence as gemm2_kernel's epilogue (common.h lmx_act; no contraction of scale and residual into
+      // one fma; an f16 result is rounded BEFORE its f16 residual is added): the two kernels serve the same shapes at
+      // different batch sizes and must agree bit for bit
+      if (p.act != LMX_ACT_NONE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act<LMX_ACT_SILU>(v[e]);
-          break;
-        case LMX_ACT_GELU:
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act<LMX_ACT_GELU>(v[e]);
-          break;
-        case LMX_ACT_RELU:
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act<LMX_ACT_RELU>(v[e]);
-          break;
-        default:
-          break;
+        for (int e = 0; e < 4; ++e) v[e] = lmx_act(v[e], p.act);
       }
       if (p.scale) {
         const f32x4 s = *reinterpret_cast<const f32x4*>(p.scale + n);
-        v *= s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(v[e], s[e]);
       }
       if (OUT_DT == LMX_F32) {
         float* C = reinterpret_cast<float*>(p.C);
         if (p.res) {
           const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)mr * p.ldr + n);
-          v += rr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], rr[e]);
         }
         *reinterpret_cast<f32x4*>(C + (int64_t)m * p.ldc + n) = v;
       } else {
@@ -222,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const lmx_gemm_desc p) {
           const half4_t rr =
               *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.res) + (int64_t)mr * p.ldr + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+          for (int e = 0; e < 4; ++e) v[e] = __fadd_rn((float)(half_t)v[e], (float)rr[e]);
         }
         half4_t o;
 #pragma unroll

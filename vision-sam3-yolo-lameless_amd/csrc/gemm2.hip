@@ -22,12 +22,7 @@
 // instantiated from another template — the library then fails to load with an undefined symbol)
 namespace lmx_gemm2 {
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == LMX_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.44269504088896340736f));
-  if (act == LMX_ACT_GELU) return gelu_1(v);
-  if (act == LMX_ACT_RELU) return fmaxf(v, 0.0f);
-  return v;
-}
+__device__ __forceinline__ float act_apply(float v, int act) { return lmx_act(v, act); }
 
 // BM x BN x BK tile, NSTAGE-slot LDS ring, (BM/64) x (BN/64) waves of 64 x 64 outputs.
 // AMODE 1: A is generated from an NHWC image batch (3x3, pad 1, stride 1|2; gemm.hip's a_mode 1) — requires Cin % BK == 0
