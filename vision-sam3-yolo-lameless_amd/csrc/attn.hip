@@ -571,6 +571,196 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(const lmx_attn_desc 
   }
 }
 
+
+// ---- whole-sequence tiles: 128 < Tk <= 208 keys and Tq <= 208 queries, head dim <= 64 (Hiera-B+ stage 3's 14 x 14 windows:
+// 196 tokens, 400 windows x 8 heads per 16-frame pass; DINOv3's 201 tokens).  attn_kernel walks these as 64-key tiles
+// with an online softmax and 128-query workgroups: 196 keys cost four tiles (the fourth holds 4 keys), 196 queries cost two
+// workgroups (the second holds 68) that each stage all of K and V — 1.7x the MFMA and softmax work and 2x the staging of
+// what the problem holds.  Here ONE workgroup owns a (window | image, head): K (13 blocks of 16 keys) and V are staged
+// once, row-major and swizzled exactly as in attn_kernel, and a wave takes the 16-query blocks two at a time (each K / V^T
+// fragment read from LDS feeds two MFMAs): S^T for ALL keys sits in the accumulators (2 x 13 x f32x4), so the softmax is
+// a plain one - max, exp2, (ones column | dot2) sum - with no running maximum and no rescale; then O^T += V^T . P^T over
+// seven 32-key k-steps.  55 KB of LDS and < 256 VGPRs: two workgroups per CU, one staging while the other computes.
+template <int QB, bool ONES>
+__global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_sp_kernel(const lmx_attn_desc p, const Geo geo) {
+  constexpr int RW = 64, CPR = 8, KB = 13, KROWS = KB * 16, VROWS = KROWS, NPASS = (KROWS + 31) / 32;
+  __shared__ __attribute__((aligned(16))) half_t Ks[KROWS * RW];
+  __shared__ __attribute__((aligned(16))) half_t Vs[VROWS * RW];  // rows Tk..207 are zeros; 2 x 26 KB: three workgroups fit a CU
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  int bid;
+  {  // XCD-aware bijective remap: the heads of one window read the same cache lines (a token row holds all heads)
+    const int n = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n >> 3, r = n & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int h = bid % p.H, b = bid / p.H;
+  const half_t* Q = reinterpret_cast<const half_t*>(p.Q);
+  const half_t* K = reinterpret_cast<const half_t*>(p.K);
+  const half_t* V = reinterpret_cast<const half_t*>(p.V);
+  const half_t* padk = reinterpret_cast<const half_t*>(p.pad_k);
+  const half_t* padv = reinterpret_cast<const half_t*>(p.pad_v);
+  half_t* O = reinterpret_cast<half_t*>(p.O);
+  const int hd = p.hd;
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- stage K and V: chunk sc of key sk + 32 i (branch-free loads, selected afterwards, as attn_kernel's load_tile)
+  {
+    const int sc = tid & (CPR - 1), sk = tid / CPR;
+    const int d = sc * 8;
+    const int64_t hoff = (int64_t)h * hd + d;
+    // two rounds (passes 0-3, then 4-6): 16 + 12 loads in flight per thread instead of 28 keeps the register peak of
+    // the staging below that of the compute phase; the other workgroups of the CU cover the second round trip
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      constexpr int H0 = 4;
+      half8_t kst[H0], vst[H0];
+#pragma unroll
+      for (int j = 0; j < H0; ++j) {
+        const int i = half * H0 + j;
+        if (i >= NPASS) continue;
+        const int t = sk + 32 * i;
+        const bool in = (t < p.Tk) && (d < hd);
+        const int64_t row = geo.mode == 0 ? (int64_t)b * p.Tk + (in ? t : 0) : key_row(geo, b, in ? t : 0);
+        const bool pad = row < 0;
+        const half_t* kp = pad ? (padk ? padk + hoff : K) : K + (in ? row * p.ldk + hoff : 0);
+        const half_t* vp = pad ? (padv ? padv + hoff : V) : V + (in ? row * p.ldv + hoff : 0);
+        const half8_t kv = *reinterpret_cast<const half8_t*>(kp);
+        const half8_t vv = *reinterpret_cast<const half8_t*>(vp);
+        kst[j] = (in && (!pad || padk)) ? kv : zero8;
+        vst[j] = (in && (!pad || padv)) ? vv : zero8;
+        if (ONES && sc == 7 && t < p.Tk) vst[j][7] = (half_t)1.0f;  // column 63 of every real key: PV sums the probabilities
+      }
+#pragma unroll
+      for (int j = 0; j < H0; ++j) {
+        const int i = half * H0 + j;
+        if (i >= NPASS) continue;
+        const int kk = sk + 32 * i;
+        const int off = kk * RW + ((sc ^ (kk & (CPR - 1))) << 3);
+        if (kk < KROWS) {
+          *reinterpret_cast<half8_t*>(&Ks[off]) = kst[j];
+          *reinterpret_cast<half8_t*>(&Vs[off]) = vst[j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  const int q4 = fr >> 2, p4 = fr & 3;
+  const int nqb = (p.Tq + 15) / 16, npair = (nqb + QB - 1) / QB;
+  for (int pr = wave; pr < npair; pr += 4) {  // no barrier below: waves run their pairs independently
+    // ---- Q fragments (B operand) of the two 16-query blocks
+    half8_t qf[QB][2];
+    int64_t qrow[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int tq = (pr * QB + qb) * 16 + fr;
+      qrow[qb] = (tq < p.Tq) ? query_row(geo, b, tq) : -1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int d = ks * 32 + fg * 8;
+        const bool ok = qrow[qb] >= 0 && d < hd;
+        const half8_t qv = *reinterpret_cast<const half8_t*>(Q + (ok ? qrow[qb] * p.ldq + (int64_t)h * hd + d : 0));
+        qf[qb][ks] = ok ? qv : zero8;
+      }
+    }
+    // ---- S^T = K . Q^T for all 13 key blocks
+    f32x4 sacc[QB][KB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) sacc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = (((ks << 2) + fg) ^ (fr & (CPR - 1))) << 3;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[(kb * 16 + fr) * RW + coff]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qb][ks], sacc[qb][kb], 0, 0, 0);
+      }
+    }
+    // ---- softmax over the whole key range (per query = per lane column), P^T fragments straight from the accumulators
+    half8_t pf[QB][7];
+    float l_sum[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+      for (int kb = 8; kb < KB; ++kb)  // Tk > 128: only blocks 8.. can hold keys >= Tk
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kb * 16 + fg * 4 + r >= p.Tk) sacc[qb][kb][r] = -INFINITY;
+      float mx = fmaxf(fmaxf(sacc[qb][0][0], sacc[qb][0][1]), fmaxf(sacc[qb][0][2], sacc[qb][0][3]));
+#pragma unroll
+      for (int kb = 1; kb < KB; ++kb)
+        mx = fmaxf(mx, fmaxf(fmaxf(sacc[qb][kb][0], sacc[qb][kb][1]), fmaxf(sacc[qb][kb][2], sacc[qb][kb][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mb = mx * sl2;
+      float rs = 0.f;
+      const half2_t ones2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+      for (int kb = 0; kb < KB + 1; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          half2_t e = {(half_t)0.0f, (half_t)0.0f};
+          if (kb < KB) {
+            const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r], sl2, -mb));
+            const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r + 1], sl2, -mb));
+            e = half2_t{(half_t)e0, (half_t)e1};
+            if (!ONES) rs = __builtin_amdgcn_fdot2(e, ones2, rs, false);  // sums exactly what the PV MFMA sees
+          }
+          pf[qb][kb >> 1][(kb & 1) * 4 + r] = e[0];
+          pf[qb][kb >> 1][(kb & 1) * 4 + r + 1] = e[1];
+        }
+      l_sum[qb] = rs;
+    }
+    // ---- O^T = V^T . P^T
+    f32x4 oacc[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int chunk = db * 2 + (p4 >> 1);
+        // keys 208..223 of the last k-step do not exist: their probabilities are zero, so any finite V row serves
+        const int r0 = ks * 32 + fg * 4 + q4, r1 = ks == 6 ? r0 : r0 + 16;
+        const half4_t lo = lds_tr_read(&Vs[r0 * RW + ((chunk ^ (r0 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
+        const half4_t hi = lds_tr_read(&Vs[r1 * RW + ((chunk ^ (r1 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
+        const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][ks], oacc[qb][db], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: lane owns O[q = fr][d = 16*db + 4*fg + r]
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float l;
+      if (ONES) {
+        l = __shfl(oacc[qb][3][3], 48 + fr, 64);  // O[q][63] lives in lane group 3, register 3 of the last d-block
+      } else {
+        l = l_sum[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+      }
+      const float inv = 1.0f / l;
+      if (qrow[qb] < 0) continue;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int d = db * 16 + fg * 4;
+        if (d >= hd) continue;
+        half4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[qb][db][r] * inv);
+        *reinterpret_cast<half4_t*>(O + qrow[qb] * p.ldo + (int64_t)h * hd + d) = o;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int build_geo(const lmx_attn_desc& d, Geo& g);
@@ -620,6 +810,23 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
     LMX_REQUIRE(items < (1ll << 31), "lmx_k_attention: grid too large");
     hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, d, g, (int)items);
     return lmx_launch_check("attn_small_kernel");
+  }
+  static int no_sp = -1;
+  if (no_sp < 0) no_sp = getenv("LMX_ATTN_NO_SP") ? 1 : 0;
+  if (!no_sp && !d.rel && d.hd <= 64 && d.Tk > 128 && d.Tk <= 208 && d.Tq > 64 && d.Tq <= 208) {  // whole sequence per workgroup
+    const int64_t items = (int64_t)d.B * d.H;
+    LMX_REQUIRE(items < (1ll << 31), "lmx_k_attention: grid too large");
+    static int sp_qb = 0;
+    if (!sp_qb) sp_qb = getenv("LMX_ATTN_SP_QB") ? atoi(getenv("LMX_ATTN_SP_QB")) : 2;
+    if (d.hd <= 56 && sp_qb == 2)
+      hipLaunchKernelGGL((attn_sp_kernel<2, true>), dim3((unsigned)items), dim3(256), 0, st, d, g);
+    else if (d.hd <= 56)
+      hipLaunchKernelGGL((attn_sp_kernel<1, true>), dim3((unsigned)items), dim3(256), 0, st, d, g);
+    else if (sp_qb == 2)
+      hipLaunchKernelGGL((attn_sp_kernel<2, false>), dim3((unsigned)items), dim3(256), 0, st, d, g);
+    else
+      hipLaunchKernelGGL((attn_sp_kernel<1, false>), dim3((unsigned)items), dim3(256), 0, st, d, g);
+    return lmx_launch_check("attn_sp_kernel");
   }
   const bool wide = d.hd > 64;  // SAM ViT-H (head dim 80): 128-half LDS rows, one 16-query block per wave
   const bool big = d.Tq > 64 && !wide;
