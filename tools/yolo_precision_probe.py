@@ -1,0 +1,36 @@
+import sys, os, numpy as np, torch
+sys.path[:0]=['/root/repo','/root/repo/vision-sam3-yolo-lameless_amd','/root/repo/tests']
+from lmx import yolo, synth
+from oracle import yolo as OY
+import keepset as KS
+scale='n'
+cfg=yolo.YoloConfig(scale); sd=yolo.synthetic_state_dict(cfg,7,f'/root/repo/tests/golden/yolov8{scale}_bn_w7.npz')
+fr=synth.synth_frame(3,40)
+ref=OY.predict(scale,80,sd,fr,conf=0.25)
+cref=KS.compact_pred(ref['pred'])
+orig_q=OY._q
+def run(mode):
+    st={'n':0}
+    def q(x):
+        st['n']+=1
+        is_w = x.dim()==4 and x.shape[2] in (1,3) and x.requires_grad is False and x.shape[0] < 2000 and st.get('in_conv',False)
+        return orig_q(x) if mode(st['n'], x) else x
+    OY._q=q
+    OY._EMULATE_F16=True
+    try:
+        r=OY.predict(scale,80,sd,fr,conf=0.25,emulate_f16=True)
+    finally:
+        OY._q=orig_q
+    c=KS.compact_pred(r['pred'])
+    es,ei,_=KS.measure_eps(cref,c,0.25)
+    firm,amb,_=KS.classify(cref,0.25,0.7,es,ei)
+    a,b=set(r['src'].tolist()),set(ref['src'].tolist())
+    return st['n'], es, ei, len(firm), len(amb), len(a^b), len(b)
+n,*r=run(lambda i,x: True); print('all', n, r)
+N=n
+print('none', run(lambda i,x: False)[1:])
+for lo,hi in [(0,N//4),(N//4,N//2),(N//2,3*N//4),(3*N//4,N)]:
+    print('only calls',lo,hi, run(lambda i,x,lo=lo,hi=hi: lo<i<=hi)[1:])
+# weights only vs activations only: weights are 4-D tensors with small spatial dims (k x k); activations have large H,W
+print('weights only', run(lambda i,x: x.dim()==4 and x.shape[-1]<=3)[1:])
+print('acts only', run(lambda i,x: not (x.dim()==4 and x.shape[-1]<=3))[1:])
