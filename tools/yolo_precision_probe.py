@@ -1,3 +1,14 @@
+"""Where does the f16 path's deviation from the fp32 YOLO oracle come from, and what would a higher-precision part buy?
+  CPU experiment on the oracle (YOLOv8-n, one synthetic 1080p frame, conf 0.25): the f16 STORAGE
+emulation of oracle.yolo is applied to a subset of the 119 rounding points (weights and stored activations, in network
+order) and the result is pushed through the keep-set margin rule (tests/keepset.py).  Output columns:
+eps_score, eps_iou, firm, ambiguous, |keep-set difference|, fp32 keep-set size.   Result (profiles/r02_yolo_precision_probe.txt):
+the FIRST quarter of the network (stem + first two stages, the high-resolution layers) alone reproduces the full
+deviation (3.8e-3); the last quarter (PAN tail + Detect head) contributes 6e-4; rounding only the weights gives 2.2e-3,
+only the activations 3.1e-3.  A higher-precision Detect head or last C2f stage therefore buys nothing measurable; shrinking
+eps by 10x needs split-f16 (hi + lo) operands for BOTH weights and activations through the whole backbone, i.e. three MFMA
+passes per GEMM = 3x YOLO's 11 % of the FLOPs (about -18 % frames/s).  Not adopted: the margin rule with the measured
+eps (3e-3 .. 6e-3) is the parity statement for the f16 path."""
 import sys, os, numpy as np, torch
 sys.path[:0]=['/root/repo','/root/repo/vision-sam3-yolo-lameless_amd','/root/repo/tests']
 from lmx import yolo, synth
