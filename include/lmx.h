@@ -257,11 +257,22 @@ int lmx_k_mask_post(const float* logits, int n, int L, int T, int nh, int nw, in
  * 8x less D2H and xGMI traffic than the byte mask. */
 int lmx_k_pack_bits(const uint8_t* src, int64_t rows, int w, uint8_t* dst, lmx_stream_t stream);
 
+/* ---- contour features ON THE DEVICE ---------------------------------------------------------
+ * The cv2 part of extract_segmentation_features (sam3 main.py:118-135): findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE),
+ * max(contours, key=contourArea), arcLength(closed), boundingRect — for n masks [n][h][w] (0 / non-0 bytes) in HBM.
+ * out int64 [n][8] = { 2 * contourArea (exact), unit steps, diagonal steps of the border chain (arcLength = unit + diag * sqrt 2),
+ * min x, min y, max x, max y of the largest external contour, number of external contours (0: all other fields 0) }.
+ * Parallel restatement of host_mask.cpp's border following as sums over boundary cracks (csrc/contour.hip); equal to it bit
+ * for bit (tests/test_gpu_contour.py).  workspace: lmx_contour_workspace_bytes(n, h, w) bytes, 16-byte aligned. */
+int64_t lmx_contour_workspace_bytes(int n, int h, int w);
+int lmx_k_contour_features(const uint8_t* mask, int n, int h, int w, int64_t* out, void* workspace, lmx_stream_t stream);
+
 /* ---- HOST function (mask pointer is HOST memory) ----------------------------------------------------------------------
  * extract_segmentation_features (sam3 main.py:102-145) on a 0/1 byte mask [h][w]: out[7] = mask_area, area_ratio,
  * circularity, aspect_ratio, centroid_x, centroid_y, perimeter.  Restates cv2.findContours(RETR_EXTERNAL,
  * CHAIN_APPROX_SIMPLE) + contourArea/arcLength/boundingRect of the largest contour + cv2.moments (cv2 absent: parity
- * unpinned).  Border following is sequential: it stays on the host. */
+ * unpinned).  Sequential border following on the host; lmx_k_contour_features is the device form (same numbers: the
+ * perimeter is unit steps + diagonal steps * sqrt 2 in both). */
 int lmx_h_mask_features(const uint8_t* mask_host, int h, int w, double* out_host);
 
 #ifdef __cplusplus

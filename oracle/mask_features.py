@@ -89,7 +89,9 @@ def features(mask):
         pts = _outer_border(m, sx, sy)
         n = len(pts)
         a2 = sum(pts[i][0] * pts[(i + 1) % n][1] - pts[(i + 1) % n][0] * pts[i][1] for i in range(n))
-        per = sum(math.dist(pts[i], pts[(i + 1) % n]) for i in range(n)) if n > 1 else 0.0
+        # chain length = unit steps + diagonal steps * sqrt 2 (counted, so that the sum does not depend on the order)
+        steps = [(abs(pts[(i + 1) % n][0] - pts[i][0]), abs(pts[(i + 1) % n][1] - pts[i][1])) for i in range(n)] if n > 1 else []
+        per = float(sum(1 for s_ in steps if s_[0] + s_[1] == 1)) + float(sum(1 for s_ in steps if s_[0] + s_[1] == 2)) * math.sqrt(2.0)
         xs, ys = [p[0] for p in pts], [p[1] for p in pts]
         cand = (abs(a2) / 2.0, per, max(xs) - min(xs) + 1, max(ys) - min(ys) + 1)
         if best is None or cand[0] > best[0]:

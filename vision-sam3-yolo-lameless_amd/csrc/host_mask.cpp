@@ -45,7 +45,8 @@ ContourStat trace_outer(const uint8_t* m, int h, int w, int sx, int sy) {
   const int x1 = sx + DX[d1], y1 = sy + DY[d1];
   int px = x1, py = y1;  // (i2,j2): previous border pixel
   int cx = sx, cy = sy;  // (i3,j3): current border pixel
-  double twice_area = 0.0, per = 0.0;
+  double twice_area = 0.0;
+  int64_t n_unit = 0, n_diag = 0;  // chain steps by length: the perimeter is n_unit + n_diag * sqrt 2 (order-free, like the device form)
   for (int64_t guard = 0; guard < (int64_t)8 * h * w + 16; ++guard) {
     // (3.3) counter-clockwise search around the current pixel, starting after the direction of the previous pixel
     int dprev = 0;
@@ -62,7 +63,10 @@ ContourStat trace_outer(const uint8_t* m, int h, int w, int sx, int sy) {
     }
     // edge current -> next contributes to the shoelace sum and the chain length
     twice_area += (double)cx * ny - (double)nx * cy;
-    per += sqrt((double)((nx - cx) * (nx - cx) + (ny - cy) * (ny - cy)));
+    if (nx != cx && ny != cy)
+      ++n_diag;
+    else if (nx != cx || ny != cy)
+      ++n_unit;
     if (nx < st.minx) st.minx = nx;
     if (nx > st.maxx) st.maxx = nx;
     if (ny < st.miny) st.miny = ny;
@@ -75,7 +79,7 @@ ContourStat trace_outer(const uint8_t* m, int h, int w, int sx, int sy) {
     cy = ny;
   }
   st.area = fabs(twice_area) * 0.5;
-  st.perimeter = per;
+  st.perimeter = (double)n_unit + (double)n_diag * 1.41421356237309504880;
   return st;
 }
 

@@ -474,6 +474,20 @@ def mask_post(logits, T, nh, nw, h, w):
     return mask, stats
 
 
+def contour_features(mask):
+    """mask u8 [n,h,w] (0 / non-0) on device -> int64 [n,8] = 2*contourArea, unit steps, diagonal steps, min x, min y, max x,
+    max y, number of external contours of the largest external contour (lmx_k_contour_features, csrc/contour.hip)."""
+    _dev(mask)
+    if mask.dtype != torch.uint8 or mask.dim() != 3 or not mask.is_contiguous():
+        raise LmxError("contour_features: mask must be contiguous uint8 [n,h,w]")
+    n, h, w = mask.shape
+    lib = _lib.load()
+    ws = torch.empty((int(lib.lmx_contour_workspace_bytes(n, h, w)),), dtype=torch.uint8, device=mask.device)
+    out = torch.empty((n, 8), dtype=torch.int64, device=mask.device)
+    check(lib.lmx_k_contour_features(_ptr(mask), n, h, w, _ptr(out), _ptr(ws), _stream()), "lmx_k_contour_features")
+    return out
+
+
 # ---- optional per-launch timing (bench.py's roofline leg) -----------------------------------------------------------
 # While a trace is active every lmx_k_* entry point is bracketed by a HIP event pair recorded on the stream the launch goes
 # to (torch's current stream of the operands' device), together with the ALGORITHMIC work of the call: flops and the minimal

@@ -29,6 +29,30 @@ def extract_segmentation_features(mask):
     return {k: float(v) for k, v in zip(FEATURE_KEYS, out)}
 
 
+def features_from_device(stats_row, contour_row, h, w):
+    """The same 7-key dict from what the DEVICE computed: stats_row = mask_post's int64 [8] (area, sum x, sum y, ...),
+    contour_row = lmx_k_contour_features' int64 [8] (2*contourArea, unit steps, diagonal steps, bbox, #external contours).
+    Same arithmetic, in the same order, as csrc/host_mask.cpp (doubles), so the two agree bit for bit."""
+    m00, m10, m01 = float(stats_row[0]), float(stats_row[1]), float(stats_row[2])
+    a2, n_unit, n_diag, minx, miny, maxx, maxy, found = (int(v) for v in contour_row)
+    out = {"mask_area": m00, "area_ratio": m00 / float(h * w) if h * w > 0 else 0.0}
+    if found > 0:
+        area = abs(a2) * 0.5
+        per = float(n_unit) + float(n_diag) * 1.41421356237309504880
+        out["circularity"] = (4.0 * 3.14159265358979323846 * area) / (per * per) if per > 0 else 0.0
+        bw, bh = maxx - minx + 1, maxy - miny + 1
+        out["aspect_ratio"] = float(bw) / float(bh) if bh > 0 else 0.0
+        perimeter = per
+    else:
+        out["circularity"], out["aspect_ratio"], perimeter = 0.0, 0.0, 0.0
+    if m00 != 0:
+        out["centroid_x"], out["centroid_y"] = m10 / m00, m01 / m00
+    else:
+        out["centroid_x"], out["centroid_y"] = w / 2.0, h / 2.0
+    out["perimeter"] = perimeter
+    return {k: float(out[k]) for k in FEATURE_KEYS}
+
+
 def fallback_segmentation(shape_hw, bbox):
     h, w = shape_hw
     mask = np.zeros((h, w), dtype=np.uint8)
