@@ -82,13 +82,14 @@ class FusedExtractor:
                    cls=torch.zeros((n, 300), dtype=torch.int32, device=dev), counts=torch.zeros((n,), dtype=torch.int32, device=dev),
                    embedding=torch.zeros((n, self.dino.cfg.hidden), dtype=torch.float32, device=dev),
                    mask_bits=torch.zeros((n, h, (w + 7) // 8), dtype=torch.uint8, device=dev),
-                   mask_stats=torch.zeros((n, 8), dtype=torch.int64, device=dev), mask_iou=torch.zeros((n,), dtype=torch.float32, device=dev),
+                   mask_stats=torch.zeros((n, 8), dtype=torch.int64, device=dev), mask_contour=torch.zeros((n, 8), dtype=torch.int64, device=dev),
+                   mask_iou=torch.zeros((n,), dtype=torch.float32, device=dev),
                    ran_det=torch.zeros((n,), dtype=torch.int32, device=dev), ran_emb=torch.zeros((n,), dtype=torch.int32, device=dev))
         fd = frames if det_idx is None else frames.index_select(0, di)
         fe = frames if emb_idx is None else frames.index_select(0, ei)
         part = self._step_dense(fd, conf, sam_chunk, keep_byte_masks, emb_frames=fe)
         if di.numel():
-            for k in ("boxes", "scores", "cls", "counts", "mask_bits", "mask_stats", "mask_iou"):
+            for k in ("boxes", "scores", "cls", "counts", "mask_bits", "mask_stats", "mask_contour", "mask_iou"):
                 out[k].index_copy_(0, di, part[k].to(out[k].dtype))
             out["ran_det"].index_fill_(0, di, 1)
             if keep_byte_masks:
@@ -131,7 +132,7 @@ class FusedExtractor:
         with torch.cuda.stream(emb_stream):
             emb = (self.dino.embed_frames(emb_frames) if emb_frames.shape[0]
                    else torch.zeros((0, self.dino.cfg.hidden), dtype=torch.float32, device=self.device))
-        masks, stats, ious = [], [], []
+        masks, stats, ious, conts = [], [], [], []
         for i, st in zip(chunks, sam_streams):  # Hiera activations are ~100 MB/frame: a chunk bounds the live set
             with torch.cuda.stream(st):
                 enc = self.sam.encode(frames[i:i + sam_chunk])
@@ -140,6 +141,8 @@ class FusedExtractor:
                 # the service prompts SAM with the first (highest-confidence) detection of the frame (sam3 main.py:199-206);
                 # frames without a detection are decoded against an all-zero box and flagged by counts == 0
                 d = self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes[i:i + sam_chunk, 0, :], (h, w), rhw)
+                # the contour part of extract_segmentation_features (sam3 main.py:118-135) on the device, on the pass's stream
+                conts.append(K.contour_features(d["mask"]))
             masks.append(d["mask"])
             stats.append(d["stats"])
             ious.append(d["iou"])
@@ -151,12 +154,13 @@ class FusedExtractor:
             out = dict(boxes=boxes, scores=scores, cls=cls, counts=counts, embedding=emb,
                        mask_bits=torch.zeros((0, h, (w + 7) // 8), dtype=torch.uint8, device=self.device),
                        mask_stats=torch.zeros((0, 8), dtype=torch.int64, device=self.device),
+                       mask_contour=torch.zeros((0, 8), dtype=torch.int64, device=self.device),
                        mask_iou=torch.zeros((0,), dtype=torch.float32, device=self.device))
         else:
             cat = (lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, 0))
             mask = cat(masks)
             out = dict(boxes=boxes, scores=scores, cls=cls, counts=counts, embedding=emb, mask_bits=K.pack_bits(mask),
-                       mask_stats=cat(stats), mask_iou=cat(ious))
+                       mask_stats=cat(stats), mask_contour=cat(conts), mask_iou=cat(ious))
         if keep_byte_masks:
             out["mask"] = mask
         return out

@@ -21,7 +21,7 @@ import torch.distributed as tdist
 
 from .. import dist as ldist
 from . import runtime as R
-from .sam3_pipeline import extract_segmentation_features
+from .sam3_pipeline import extract_segmentation_features, features_from_device
 from .yolo_pipeline import detections_from_device
 
 
@@ -111,6 +111,7 @@ class FusedFeatureService:
         return dict(boxes=z((0, 300, 4), device=dev), scores=z((0, 300), device=dev), cls=z((0, 300), dtype=torch.int32, device=dev),
                     counts=z((0,), dtype=torch.int32, device=dev), embedding=z((0, D), device=dev),
                     mask_bits=z((0, h, (w + 7) // 8), dtype=torch.uint8, device=dev), mask_stats=z((0, 8), dtype=torch.int64, device=dev),
+                    mask_contour=z((0, 8), dtype=torch.int64, device=dev),
                     mask_iou=z((0,), device=dev), ran_det=z((0,), dtype=torch.int32, device=dev),
                     ran_emb=z((0,), dtype=torch.int32, device=dev), frame_id=z((0,), dtype=torch.int64, device=dev))
 
@@ -132,13 +133,18 @@ class FusedFeatureService:
         yolo_results = self.yolo.results_from_detections(dets, total, fps)
         await self.yolo.write_and_publish(video_id, yolo_results)
         self.sam3.yolo_results_cache[video_id] = yolo_results
-        # sam3: a mask exists where YOLO found something (the prompt is its first box); features from the host copy of the bits
-        w = clip.frame_hw[1]
+        # sam3: a mask exists where YOLO found something (the prompt is its first box).  The 7 features come from what the
+        # device computed (mask_post's statistics + lmx_k_contour_features): the mask itself never leaves the GPU; an
+        # extractor without the contour record falls back to the host border following on the unpacked bits
+        h, w = clip.frame_hw
         feats = {}
         for j in det_rows:
             if int(host["counts"][j]) > 0:
-                m = np.unpackbits(host["mask_bits"][j].numpy(), axis=-1, count=w).astype(bool)
-                feats[fid[j]] = extract_segmentation_features(m)
+                if "mask_contour" in host:
+                    feats[fid[j]] = features_from_device(host["mask_stats"][j].tolist(), host["mask_contour"][j].tolist(), h, w)
+                else:
+                    m = np.unpackbits(host["mask_bits"][j].numpy(), axis=-1, count=w).astype(bool)
+                    feats[fid[j]] = extract_segmentation_features(m)
         await self.sam3.write_and_publish(video_id, self.sam3.results_from_features([fid[j] for j in det_rows], fps, total, feats))
         # dinov3
         embs = [{"frame": fid[j], "time": fid[j] / fps if fps > 0 else 0, "embedding": host["embedding"][j].numpy().tolist()}

@@ -86,20 +86,20 @@ class SAM3Pipeline:
             return res
         return {}
 
-    def _masks(self, frames_host, boxes):
-        """frames_host uint8 [k,h,w,3] + their boxes -> list of host bool masks."""
+    def _features(self, frames_host, boxes):
+        """frames_host uint8 [k,h,w,3] + their boxes -> list of the 7-key feature dicts of extract_segmentation_features.
+        With a segmenter the mask stays on the GPU (statistics from mask_post, contour features from lmx_k_contour_features,
+        128 bytes per frame come back); the rectangle fallback (no checkpoint / failing segmenter, main.py:90-100) is host code."""
         h, w = frames_host.shape[1:3]
-        if self.sam_predictor is None:
-            return [fallback_segmentation((h, w), b) for b in boxes]
-        try:
-            dev = self.sam_predictor.device
-            m = self.sam_predictor.segment(torch.from_numpy(frames_host).to(dev), torch.tensor(boxes, dtype=torch.float32, device=dev))
-            # 8x less D2H: the device packs the mask (numpy.packbits order), the host unpacks it
-            bits = K.pack_bits(m).cpu().numpy()
-            return [a.astype(bool) for a in np.unpackbits(bits, axis=-1, count=m.shape[-1])]
-        except Exception as e:  # noqa: BLE001 — main.py:90-92: a failing segmenter falls back to the rectangle
-            print(f"SAM3 segmentation error: {e}")
-            return [fallback_segmentation((h, w), b) for b in boxes]
+        if self.sam_predictor is not None:
+            try:
+                dev = self.sam_predictor.device
+                out = self.sam_predictor.segment_records(torch.from_numpy(frames_host).to(dev), torch.tensor(boxes, dtype=torch.float32, device=dev))
+                stats, cont = out["stats"].cpu().tolist(), out["contour"].cpu().tolist()
+                return [features_from_device(stats[i], cont[i], h, w) for i in range(len(boxes))]
+            except Exception as e:  # noqa: BLE001 — main.py:90-92: a failing segmenter falls back to the rectangle
+                print(f"SAM3 segmentation error: {e}")
+        return [extract_segmentation_features(fallback_segmentation((h, w), b)) for b in boxes]
 
     @staticmethod
     def first_boxes(yolo_results):
@@ -158,8 +158,8 @@ class SAM3Pipeline:
 
             def flush():
                 if pend_ids:
-                    for i, m in zip(pend_ids, self._masks(np.stack(pend_frames, 0), [by_frame[i] for i in pend_ids])):
-                        feats[i] = extract_segmentation_features(m)
+                    for i, f in zip(pend_ids, self._features(np.stack(pend_frames, 0), [by_frame[i] for i in pend_ids])):
+                        feats[i] = f
                     pend_ids.clear()
                     pend_frames.clear()
 
@@ -189,13 +189,18 @@ class HieraSegmenter:
         self.encoder, self.decoder = encoder, decoder
         self.device = encoder.device
 
-    def segment(self, frames, boxes):
+    def segment_records(self, frames, boxes):
+        """-> dict(mask u8 [n,h,w], stats int64 [n,8], contour int64 [n,8], iou f32 [n]) on the device."""
         from .. import sam
 
         n, h, w, _ = frames.shape
         enc = self.encoder.encode(frames)
         e2 = enc["fpn"][2]
-        return self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes, (h, w), sam.resize_longest_side(h, w, self.encoder.cfg.image))["mask"]
+        d = self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes, (h, w), sam.resize_longest_side(h, w, self.encoder.cfg.image))
+        return dict(mask=d["mask"], stats=d["stats"], contour=K.contour_features(d["mask"]), iou=d["iou"])
+
+    def segment(self, frames, boxes):
+        return self.segment_records(frames, boxes)["mask"]
 
 
 SamSegmenter = HieraSegmenter  # the adapter only relies on encode(...)["fpn"][2] being the [n,64,64,256] embedding
