@@ -171,118 +171,140 @@ __global__ __launch_bounds__(256) void contour_sum_kernel(const uint8_t* __restr
     const int first = __ffsll((long long)bal) - 1;
     const int root0 = __shfl(root, first, 64);
     const int img0 = __shfl(img, first, 64);
-    const bool uniform = __ballot(has && (root != root0 || img != img0)) == 0;
-    if (uniform) {
-      long long s2 = has ? a2 : 0;
-      unsigned long long ss = has ? st : 0;
+    // the lanes that share the first contributor's component reduce together (one atomic pair); the others — cracks of
+    // isolated noise pixels and small neighbours — add on their own, to addresses of their own
+    const bool grp = has && root == root0 && img == img0;
+    long long s2 = grp ? a2 : 0;
+    unsigned long long ss = grp ? st : 0;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        s2 += __shfl_xor(s2, o, 64);
-        ss += __shfl_xor(ss, o, 64);
-      }
-      if (lane == first) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(acc.area2 + (int64_t)img0 * npix + root0), (unsigned long long)s2);
-        atomicAdd(acc.steps + (int64_t)img0 * npix + root0, ss);
-      }
-    } else if (has) {
+    for (int o = 32; o > 0; o >>= 1) {
+      s2 += __shfl_xor(s2, o, 64);
+      ss += __shfl_xor(ss, o, 64);
+    }
+    if (lane == first) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc.area2 + (int64_t)img0 * npix + root0), (unsigned long long)s2);
+      atomicAdd(acc.steps + (int64_t)img0 * npix + root0, ss);
+    } else if (has && !grp) {
       atomicAdd(reinterpret_cast<unsigned long long*>(acc.area2 + (int64_t)img * npix + root), (unsigned long long)a2);
       atomicAdd(acc.steps + (int64_t)img * npix + root, st);
     }
   }
 }
 
-// bounding box of every EXTERNAL component: min / max over its pixels that own a crack = its extreme pixels
-__global__ __launch_bounds__(256) void contour_bbox_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ L, int* __restrict__ bbox,
-                                                           int n, int h, int w, int64_t npix) {
+// per-frame scratch: best = max over external roots of (|area2| << 21 | (0x1fffff - root)) -> largest area, first in raster
+// order among equals; count = number of external contours; box = min x, min y, max x, max y of the winner
+struct Sel {
+  unsigned long long* best;  // [n]
+  int* count;                // [n]
+  int* box;                  // [n][4]
+};
+
+// every root of an EXTERNAL component (its west neighbour is outside background or the frame) bids for its frame
+__global__ __launch_bounds__(256) void contour_select_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ L, Acc acc, Sel sel,
+                                                             int n, int w, int64_t npix) {
   const int64_t total = (int64_t)n * npix;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int img = (int)(g / npix);
     const int i = (int)(g - (int64_t)img * npix);
     const uint8_t* m = mask + (int64_t)img * npix;
     if (m[i] == 0) continue;
-    const int y = i / w, x = i - y * w;
-    // only pixels with a background or frame 4-neighbour can be extreme
-    const bool edge = x == 0 || y == 0 || x == w - 1 || y == h - 1 || m[i - 1] == 0 || m[i + 1] == 0 || m[i - w] == 0 || m[i + w] == 0;
-    if (!edge) continue;
-    int* bb = bbox + ((int64_t)img * npix + L[(int64_t)img * (npix + 1) + i]) * 4;
-    atomicMin(bb + 0, x);
-    atomicMin(bb + 1, y);
-    atomicMax(bb + 2, x);
-    atomicMax(bb + 3, y);
-  }
-}
-
-// one workgroup per frame: the external component (root whose west neighbour is outside background or the frame) with the
-// largest |area2|, first in raster order among equals  ->  out[8] = area2 (>= 0), unit steps, diagonal steps, min x, min y,
-// max x, max y, number of external contours
-__global__ __launch_bounds__(256) void contour_select_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ L, Acc acc,
-                                                             const int* __restrict__ bbox, long long* __restrict__ out, int h, int w,
-                                                             int64_t npix) {
-  const int img = blockIdx.x;
-  const uint8_t* m = mask + (int64_t)img * npix;
-  const int* Li = L + (int64_t)img * (npix + 1);
-  const int outside = Li[npix];
-  long long best_a = -1;
-  int best_r = 0x7fffffff, count = 0;
-  for (int i = threadIdx.x; i < npix; i += blockDim.x) {
-    if (m[i] == 0 || Li[i] != i) continue;  // roots only
+    const int* Li = L + (int64_t)img * (npix + 1);
+    if (Li[i] != i) continue;  // roots only: the first pixel of a component in raster order
     const int x = i % w;
-    const bool external = x == 0 || (m[i - 1] == 0 && Li[i - 1] == outside);
-    if (!external) continue;
-    ++count;
+    if (!(x == 0 || (m[i - 1] == 0 && Li[i - 1] == Li[npix]))) continue;
     long long a = acc.area2[(int64_t)img * npix + i];
     a = a < 0 ? -a : a;
-    if (a > best_a || (a == best_a && i < best_r)) {
-      best_a = a;
-      best_r = i;
-    }
+    atomicMax(sel.best + img, ((unsigned long long)a << 21) | (unsigned long long)(0x1fffff - i));
+    atomicAdd(sel.count + img, 1);
   }
-  __shared__ long long sa[256];
-  __shared__ int sr[256], sc[256];
-  sa[threadIdx.x] = best_a;
-  sr[threadIdx.x] = best_r;
-  sc[threadIdx.x] = count;
+}
+
+// bounding box of the winner: min / max over its pixels that touch background or the frame (its extreme pixels do).
+// grid (blocks per frame, frames): a thread keeps its extremes over its whole grid-stride walk of ONE frame, the block reduces
+// them, and one thread issues at most four atomics — same-address atomics serialise at the memory side, and a per-wave
+// version of this kernel spent 0.9 ms per 16 noisy masks on them
+__global__ __launch_bounds__(256) void contour_box_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ L, Sel sel, int h, int w,
+                                                          int64_t npix) {
+  const int img = blockIdx.y;
+  if (sel.count[img] == 0) return;
+  const int win = 0x1fffff - (int)(sel.best[img] & 0x1fffffull);
+  const uint8_t* m = mask + (int64_t)img * npix;
+  const int* Li = L + (int64_t)img * (npix + 1);
+  int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+    if (m[i] == 0 || Li[i] != win) continue;
+    const int y = i / w, x = i - y * w;
+    const bool edge = x == 0 || y == 0 || x == w - 1 || y == h - 1 || m[i - 1] == 0 || m[i + 1] == 0 || m[i - w] == 0 || m[i + w] == 0;
+    if (!edge) continue;
+    mnx = min(mnx, x);
+    mny = min(mny, y);
+    mxx = max(mxx, x);
+    mxy = max(mxy, y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = min(mnx, __shfl_xor(mnx, o, 64));
+    mny = min(mny, __shfl_xor(mny, o, 64));
+    mxx = max(mxx, __shfl_xor(mxx, o, 64));
+    mxy = max(mxy, __shfl_xor(mxy, o, 64));
+  }
+  __shared__ int red[4][4];
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wv][0] = mnx;
+    red[wv][1] = mny;
+    red[wv][2] = mxx;
+    red[wv][3] = mxy;
+  }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) {
-      const long long a = sa[threadIdx.x + o];
-      const int r = sr[threadIdx.x + o];
-      if (a > sa[threadIdx.x] || (a == sa[threadIdx.x] && r < sr[threadIdx.x])) {
-        sa[threadIdx.x] = a;
-        sr[threadIdx.x] = r;
-      }
-      sc[threadIdx.x] += sc[threadIdx.x + o];
-    }
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
-    long long* o = out + (int64_t)img * 8;
-    if (sa[0] < 0) {
-      for (int k = 0; k < 8; ++k) o[k] = 0;
-    } else {
-      const int r = sr[0];
-      const unsigned long long st = acc.steps[(int64_t)img * npix + r];
-      const int* bb = bbox + ((int64_t)img * npix + r) * 4;
-      o[0] = sa[0];
-      o[1] = (long long)(st & 0xffffffffull);
-      o[2] = (long long)(st >> 32);
-      o[3] = bb[0];
-      o[4] = bb[1];
-      o[5] = bb[2];
-      o[6] = bb[3];
-      o[7] = sc[0];
+    for (int k = 1; k < 4; ++k) {
+      mnx = min(mnx, red[k][0]);
+      mny = min(mny, red[k][1]);
+      mxx = max(mxx, red[k][2]);
+      mxy = max(mxy, red[k][3]);
+    }
+    int* bb = sel.box + img * 4;
+    if (mxx >= 0) {
+      atomicMin(bb + 0, mnx);
+      atomicMin(bb + 1, mny);
+      atomicMax(bb + 2, mxx);
+      atomicMax(bb + 3, mxy);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void bbox_init_kernel(int* __restrict__ bbox, int64_t count) {
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += (int64_t)gridDim.x * blockDim.x) {
-    int* bb = bbox + g * 4;
-    bb[0] = 0x7fffffff;
-    bb[1] = 0x7fffffff;
-    bb[2] = -1;
-    bb[3] = -1;
+__global__ void contour_sel_init_kernel(Sel sel, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sel.best[i] = 0;
+  sel.count[i] = 0;
+  sel.box[i * 4 + 0] = 0x7fffffff;
+  sel.box[i * 4 + 1] = 0x7fffffff;
+  sel.box[i * 4 + 2] = -1;
+  sel.box[i * 4 + 3] = -1;
+}
+
+// out[8] = area2 (>= 0), unit steps, diagonal steps, min x, min y, max x, max y, number of external contours
+__global__ void contour_final_kernel(Acc acc, Sel sel, long long* __restrict__ out, int n, int64_t npix) {
+  const int img = blockIdx.x * blockDim.x + threadIdx.x;
+  if (img >= n) return;
+  long long* o = out + (int64_t)img * 8;
+  if (sel.count[img] == 0) {
+    for (int k = 0; k < 8; ++k) o[k] = 0;
+    return;
   }
+  const unsigned long long key = sel.best[img];
+  const int r = 0x1fffff - (int)(key & 0x1fffffull);
+  const unsigned long long st = acc.steps[(int64_t)img * npix + r];
+  o[0] = (long long)(key >> 21);
+  o[1] = (long long)(st & 0xffffffffull);
+  o[2] = (long long)(st >> 32);
+  o[3] = sel.box[img * 4 + 0];
+  o[4] = sel.box[img * 4 + 1];
+  o[5] = sel.box[img * 4 + 2];
+  o[6] = sel.box[img * 4 + 3];
+  o[7] = sel.count[img];
 }
 
 inline unsigned grid_for(int64_t items) {
@@ -293,17 +315,18 @@ inline unsigned grid_for(int64_t items) {
 
 }  // namespace
 
-// labels (npix + 1 ints) + area2 (8 B) + steps (8 B) + bbox (16 B) per pixel and frame
+// labels (npix + 1 ints) + area2 (8 B) + steps (8 B) per pixel and frame, + 32 B of selection scratch per frame
 extern "C" int64_t lmx_contour_workspace_bytes(int n, int h, int w) {
   if (n <= 0 || h <= 0 || w <= 0) return 0;
   const int64_t npix = (int64_t)h * w;
-  return (int64_t)n * ((npix + 1) * 4 + npix * 32) + 256;
+  return (int64_t)n * ((npix + 1) * 4 + npix * 16 + 32) + 256;
 }
 
 extern "C" int lmx_k_contour_features(const uint8_t* mask, int n, int h, int w, int64_t* out, void* workspace, lmx_stream_t stream) {
   LMX_REQUIRE(mask && out && workspace, "lmx_k_contour_features: null pointer");
-  LMX_REQUIRE(n > 0 && h > 1 && w > 1 && (int64_t)h * w < 0x7ffffff0ll && w <= 65536 && (int64_t)n * h < 0x7fffffffll,
-              "lmx_k_contour_features: n=%d h=%d w=%d", n, h, w);
+  // (the selection key packs the root index into 21 bits: 1080p = 2 073 600 pixels < 2^21)
+  LMX_REQUIRE(n > 0 && h > 1 && w > 1 && (int64_t)h * w <= 0x1fffff && (int64_t)n * h < 0x7fffffffll && n <= 65535,
+              "lmx_k_contour_features: n=%d h=%d w=%d (at most 2^21 - 1 pixels per mask)", n, h, w);
   LMX_REQUIRE(aligned16(workspace), "lmx_k_contour_features: workspace alignment");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t npix = (int64_t)h * w;
@@ -315,15 +338,24 @@ extern "C" int lmx_k_contour_features(const uint8_t* mask, int n, int h, int w, 
   off += (int64_t)n * npix * 8;
   acc.steps = reinterpret_cast<unsigned long long*>(ws + off);
   off += (int64_t)n * npix * 8;
-  int* bbox = reinterpret_cast<int*>(ws + off);
+  Sel sel;
+  sel.best = reinterpret_cast<unsigned long long*>(ws + off);
+  off += (int64_t)n * 8;
+  sel.count = reinterpret_cast<int*>(ws + off);
+  off += (((int64_t)n * 4) + 15) & ~15ll;
+  sel.box = reinterpret_cast<int*>(ws + off);
   LMX_HIP(hipMemsetAsync(acc.area2, 0, (size_t)n * npix * 16, st));  // area2 and steps are adjacent
-  hipLaunchKernelGGL(bbox_init_kernel, dim3(grid_for((int64_t)n * npix)), dim3(256), 0, st, bbox, (int64_t)n * npix);
+  hipLaunchKernelGGL(contour_sel_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, sel, n);
   hipLaunchKernelGGL(cc_rows_kernel, dim3((unsigned)((int64_t)n * h)), dim3(256), 0, st, mask, L, h, w, npix);
   hipLaunchKernelGGL(cc_union_kernel, dim3(grid_for((int64_t)n * npix)), dim3(256), 0, st, mask, L, n, h, w, npix);
   hipLaunchKernelGGL(cc_compress_kernel, dim3(grid_for((int64_t)n * (npix + 1))), dim3(256), 0, st, L, n, npix);
   hipLaunchKernelGGL(contour_sum_kernel, dim3(grid_for((int64_t)n * npix)), dim3(256), 0, st, mask, L, acc, n, h, w, npix);
-  hipLaunchKernelGGL(contour_bbox_kernel, dim3(grid_for((int64_t)n * npix)), dim3(256), 0, st, mask, L, bbox, n, h, w, npix);
-  hipLaunchKernelGGL(contour_select_kernel, dim3((unsigned)n), dim3(256), 0, st, mask, L, acc, bbox, reinterpret_cast<long long*>(out), h, w,
-                     npix);
-  return lmx_launch_check("contour_select_kernel");
+  hipLaunchKernelGGL(contour_select_kernel, dim3(grid_for((int64_t)n * npix)), dim3(256), 0, st, mask, L, acc, sel, n, w, npix);
+  {
+    int64_t gx = (npix + 255) / 256;
+    if (gx > 64) gx = 64;  // 64 blocks x 4 same-address atomics per frame
+    hipLaunchKernelGGL(contour_box_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, st, mask, L, sel, h, w, npix);
+  }
+  hipLaunchKernelGGL(contour_final_kernel, dim3((n + 63) / 64), dim3(64), 0, st, acc, sel, reinterpret_cast<long long*>(out), n, npix);
+  return lmx_launch_check("contour_final_kernel");
 }
