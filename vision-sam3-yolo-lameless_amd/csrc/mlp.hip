@@ -25,9 +25,15 @@ constexpr int HC = 32;   // hidden units per chunk (one MFMA k-step of the secon
 // D: token width (multiple of 16, <= 256).  NW waves of QB 16-token blocks: a workgroup owns NW*16*QB tokens.
 // Every wave issues PT LDS-DMA instructions (1 KB each) per chunk: NW*PT KB = one ring slot = [W1 chunk | W2 chunk].
 // NST: LDS ring slots (NST-1 chunks in flight).  OCC: workgroups per CU the register budget must allow.
-template <int D, int QB, int NW, int NST, int OCC>
+// INLN: the LayerNorm runs in this kernel (row statistics reduced over the four lanes of a token) instead of reading the f16
+// rows a LayerNorm launch wrote: saves that launch and 4D bytes per token.  Round 1 had to take it out — a few hundred rows
+// per million got run-to-run different statistics whenever MFMA waves shared the SIMD; round 2 traced that to the SLP
+// vectoriser's v_pk_add_f32 op_sel:[0,1] in the horizontal sums, which the build now forbids.
+template <int D, int QB, int NW, int NST, int OCC, bool INLN>
 __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __restrict__ x, int64_t ldx,
                                                                           const half_t* __restrict__ hn,
+                                                                          const float* __restrict__ gam,
+                                                                          const float* __restrict__ bet, const float eps,
                                                                           const half_t* __restrict__ w1,
                                                                           const float* __restrict__ b1,
                                                                           const half_t* __restrict__ w2,
@@ -97,13 +103,60 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int64_t t = tok0 + qb * 16 + fr;
-    const half_t* hr = hn + (t < rows ? t : 0) * D;
+    if constexpr (INLN) {
+      // LayerNorm straight into MFMA B-operand fragments: a token's D features sit in the 4 lanes fr, fr+16, fr+32, fr+48.
+      // Three passes over the (L1/L2-hot) row instead of holding its D/4 values per lane keep the prologue's register peak
+      // below the main loop's.
+      const float* xr = x + (t < rows ? t : 0) * ldx;
+      float s = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int d = ks * 32 + fg * 8;
-      const bool ok = d < D;  // D % 8 == 0: a lane's 8 features are all in or all out
-      const half8_t v = *reinterpret_cast<const half8_t*>(hr + (ok ? d : 0));
-      xn[qb][ks] = ok ? v : zero8;
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d = ks * 32 + fg * 8;
+        if (d < D) {  // D % 8 == 0: a lane's 8 features are all in or all out
+          const f32x4 a = *reinterpret_cast<const f32x4*>(xr + d), b = *reinterpret_cast<const f32x4*>(xr + d + 4);
+          s += (a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3]);
+        }
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d = ks * 32 + fg * 8;
+        if (d < D) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(xr + d) - mean, b = *reinterpret_cast<const f32x4*>(xr + d + 4) - mean;
+          q += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
+        }
+      }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = __builtin_amdgcn_rsqf(q * (1.0f / D) + eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d = ks * 32 + fg * 8;
+        const bool ok = d < D;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam + (ok ? d : 0)), g1 = *reinterpret_cast<const f32x4*>(gam + (ok ? d + 4 : 0));
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(bet + (ok ? d : 0)), c1 = *reinterpret_cast<const f32x4*>(bet + (ok ? d + 4 : 0));
+        const f32x4 va = *reinterpret_cast<const f32x4*>(xr + (ok ? d : 0)), vb = *reinterpret_cast<const f32x4*>(xr + (ok ? d + 4 : 0));
+        half8_t hh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hh[e] = (half_t)(ok ? (va[e] - mean) * rstd * g0[e] + c0[e] : 0.f);
+          hh[4 + e] = (half_t)(ok ? (vb[e] - mean) * rstd * g1[e] + c1[e] : 0.f);
+        }
+        xn[qb][ks] = hh;
+      }
+    } else {
+      // the normalised tokens (f16) written by the LayerNorm launch that precedes this kernel
+      const half_t* hr = hn + (t < rows ? t : 0) * D;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d = ks * 32 + fg * 8;
+        const bool ok = d < D;  // D % 8 == 0: a lane's 8 features are all in or all out
+        const half8_t v = *reinterpret_cast<const half8_t*>(hr + (ok ? d : 0));
+        xn[qb][ks] = ok ? v : zero8;
+      }
     }
   }
 
@@ -203,21 +256,22 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
   }
 }
 
-template <int D, int QB, int NW, int NST, int OCC>
-int launch(float* x, int64_t ldx, const half_t* hn, const half_t* w1, const float* b1, const half_t* w2, const float* b2, int64_t rows,
-           hipStream_t st) {
+template <int D, int QB, int NW, int NST, int OCC, bool INLN>
+int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const float* bet, float eps, const half_t* w1, const float* b1,
+           const half_t* w2, const float* b2, int64_t rows, hipStream_t st) {
   constexpr int DP = D <= 128 ? 128 : 256;
   const size_t smem = (size_t)NST * (HC * DP * 2 + DP * 64) + 4 * D * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mlp_kernel<D, QB, NW, NST, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mlp_kernel<D, QB, NW, NST, OCC, INLN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
     attr_set = true;
   }
   const int64_t per = NW * 16 * QB;
   const int64_t nb = (rows + per - 1) / per;
   LMX_REQUIRE(nb < 0x7fffffffll, "lmx_k_ln_mlp: too many rows");
-  hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, hn, w1, b1, w2, b2, rows);
+  hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC, INLN>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, hn, gam, bet, eps, w1, b1, w2,
+                     b2, rows);
   return lmx_launch_check("ln_mlp_kernel");
 }
 
@@ -234,16 +288,24 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
                   aligned16(workspace),
               "lmx_k_ln_mlp: pointers must be 16-byte aligned");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const half_t* W1 = reinterpret_cast<const half_t*>(w1);
+  const half_t* W2 = reinterpret_cast<const half_t*>(w2);
+  static int one_per_cu = -1, split_ln = 0;  // LMX_MLP_ONE_PER_CU=1: the 8-wave, one-workgroup-per-CU configuration of the narrow width too
+  if (one_per_cu < 0) {
+    one_per_cu = getenv("LMX_MLP_ONE_PER_CU") ? 1 : 0;
+    split_ln = getenv("LMX_MLP_SPLIT_LN") ? 1 : 0;  // the round-1 form: a LayerNorm launch into the workspace, then the fused MLP on it
+  }
+  // D = 112: 4 waves x 32 tokens, 48 KB ring, three workgroups per CU.  D = 224: 8 waves x 32 tokens, 128 KB ring, one per CU.
+  if (!split_ln) {
+    if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, st);
+    if (D == 112) return launch<112, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, st);
+    return launch<224, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, st);
+  }
   // 1. LayerNorm (norm.hip; f32 stream -> f16 [rows, D] in the workspace), 2. the fused MLP + residual on it
   const int rc = lmx_k_layernorm(x, LMX_F32, ldx, gamma, beta, workspace, LMX_F16, D, (int)rows, D, eps, LMX_ACT_NONE, stream);
   if (rc) return rc;
   const half_t* hn = reinterpret_cast<const half_t*>(workspace);
-  const half_t* W1 = reinterpret_cast<const half_t*>(w1);
-  const half_t* W2 = reinterpret_cast<const half_t*>(w2);
-  static int one_per_cu = -1;  // LMX_MLP_ONE_PER_CU=1: the 8-wave, one-workgroup-per-CU configuration of the narrow width too
-  if (one_per_cu < 0) one_per_cu = getenv("LMX_MLP_ONE_PER_CU") ? 1 : 0;
-  // D = 112: 4 waves x 32 tokens, 48 KB ring, three workgroups per CU.  D = 224: 8 waves x 32 tokens, 128 KB ring, one per CU.
-  if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3>(x, ldx, hn, W1, b1, W2, b2, rows, st);
-  if (D == 112) return launch<112, 2, 8, 4, 1>(x, ldx, hn, W1, b1, W2, b2, rows, st);
-  return launch<224, 2, 8, 4, 1>(x, ldx, hn, W1, b1, W2, b2, rows, st);
+  if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, st);
+  if (D == 112) return launch<112, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, st);
+  return launch<224, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, st);
 }
