@@ -102,21 +102,34 @@ __global__ __launch_bounds__(256) void cc_union_kernel(const uint8_t* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void cc_compress_kernel(int* __restrict__ L, int n, int64_t npix) {
+struct Acc {
+  long long* area2;           // [n][npix] sum of cross terms, indexed by root pixel (initialised at roots only)
+  unsigned long long* steps;  // [n][npix] unit steps in the low 32 bits, diagonal steps in the high 32
+  int* box;                   // [n][npix][4] min x, min y, max x, max y of the component's pixels that own a crack
+};
+
+// path compression; a root (the first pixel of a component) also clears its accumulators — the arrays are indexed by root
+// pixel and only ever touched there, so nothing else of their 32 bytes per pixel needs initialising
+__global__ __launch_bounds__(256) void cc_compress_kernel(int* __restrict__ L, Acc acc, int n, int64_t npix) {
   const int64_t total = (int64_t)n * (npix + 1);
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int img = (int)(g / (npix + 1));
     const int i = (int)(g - (int64_t)img * (npix + 1));
     int* Li = L + (int64_t)img * (npix + 1);
     const int r = uf_find(Li, i);
-    if (r != i) __hip_atomic_store(Li + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // only ever shortens a path
+    if (r != i) {
+      __hip_atomic_store(Li + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // only ever shortens a path
+    } else if (i < npix) {
+      const int64_t k = (int64_t)img * npix + i;
+      acc.area2[k] = 0;
+      acc.steps[k] = 0;
+      acc.box[k * 4 + 0] = 0x7fffffff;
+      acc.box[k * 4 + 1] = 0x7fffffff;
+      acc.box[k * 4 + 2] = -1;
+      acc.box[k * 4 + 3] = -1;
+    }
   }
 }
-
-struct Acc {
-  long long* area2;           // [n][npix] sum of cross terms, indexed by root pixel
-  unsigned long long* steps;  // [n][npix] unit steps in the low 32 bits, diagonal steps in the high 32
-};
 
 // crack sums.  A thread owns one foreground pixel and its (up to four) cracks.
 __global__ __launch_bounds__(256) void contour_sum_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ L, Acc acc, int n, int h,
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(256) void contour_sum_kernel(const uint8_t* __restr
     const int64_t g = base + lane;
     long long a2 = 0;
     unsigned long long st = 0;
-    int root = -1, img = 0;
+    int root = -1, img = 0, px = 0, py = 0;
     if (g < total) {
       img = (int)(g / npix);
       const int i = (int)(g - (int64_t)img * npix);
@@ -161,6 +174,8 @@ __global__ __launch_bounds__(256) void contour_sum_kernel(const uint8_t* __restr
           }
           a2 += (long long)x * ny - (long long)nx * y;
           root = Li[i];
+          px = x;
+          py = y;
         }
       }
     }
@@ -176,27 +191,45 @@ __global__ __launch_bounds__(256) void contour_sum_kernel(const uint8_t* __restr
     const bool grp = has && root == root0 && img == img0;
     long long s2 = grp ? a2 : 0;
     unsigned long long ss = grp ? st : 0;
+    int mnx = grp ? px : 0x7fffffff, mny = grp ? py : 0x7fffffff, mxx = grp ? px : -1, mxy = grp ? py : -1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       s2 += __shfl_xor(s2, o, 64);
       ss += __shfl_xor(ss, o, 64);
+      mnx = min(mnx, __shfl_xor(mnx, o, 64));
+      mny = min(mny, __shfl_xor(mny, o, 64));
+      mxx = max(mxx, __shfl_xor(mxx, o, 64));
+      mxy = max(mxy, __shfl_xor(mxy, o, 64));
     }
+    int64_t k = -1;
     if (lane == first) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(acc.area2 + (int64_t)img0 * npix + root0), (unsigned long long)s2);
-      atomicAdd(acc.steps + (int64_t)img0 * npix + root0, ss);
+      k = (int64_t)img0 * npix + root0;
     } else if (has && !grp) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(acc.area2 + (int64_t)img * npix + root), (unsigned long long)a2);
-      atomicAdd(acc.steps + (int64_t)img * npix + root, st);
+      k = (int64_t)img * npix + root;
+      s2 = a2;
+      ss = st;
+      mnx = mxx = px;
+      mny = mxy = py;
+    }
+    if (k >= 0) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(acc.area2 + k), (unsigned long long)s2);
+      atomicAdd(acc.steps + k, ss);
+      // the box only grows: an atomic that cannot grow it is skipped after a plain (possibly stale = less grown) look
+      int* bb = acc.box + k * 4;
+      const volatile int* vb = bb;
+      if (mnx < vb[0]) atomicMin(bb + 0, mnx);
+      if (mny < vb[1]) atomicMin(bb + 1, mny);
+      if (mxx > vb[2]) atomicMax(bb + 2, mxx);
+      if (mxy > vb[3]) atomicMax(bb + 3, mxy);
     }
   }
 }
 
 // per-frame scratch: best = max over external roots of (|area2| << 21 | (0x1fffff - root)) -> largest area, first in raster
-// order among equals; count = number of external contours; box = min x, min y, max x, max y of the winner
+// order among equals; count = number of external contours
 struct Sel {
   unsigned long long* best;  // [n]
   int* count;                // [n]
-  int* box;                  // [n][4]
 };
 
 // every root of an EXTERNAL component (its west neighbour is outside background or the frame) bids for its frame
@@ -219,70 +252,11 @@ __global__ __launch_bounds__(256) void contour_select_kernel(const uint8_t* __re
   }
 }
 
-// bounding box of the winner: min / max over its pixels that touch background or the frame (its extreme pixels do).
-// grid (blocks per frame, frames): a thread keeps its extremes over its whole grid-stride walk of ONE frame, the block reduces
-// them, and one thread issues at most four atomics — same-address atomics serialise at the memory side, and a per-wave
-// version of this kernel spent 0.9 ms per 16 noisy masks on them
-__global__ __launch_bounds__(256) void contour_box_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ L, Sel sel, int h, int w,
-                                                          int64_t npix) {
-  const int img = blockIdx.y;
-  if (sel.count[img] == 0) return;
-  const int win = 0x1fffff - (int)(sel.best[img] & 0x1fffffull);
-  const uint8_t* m = mask + (int64_t)img * npix;
-  const int* Li = L + (int64_t)img * (npix + 1);
-  int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-    if (m[i] == 0 || Li[i] != win) continue;
-    const int y = i / w, x = i - y * w;
-    const bool edge = x == 0 || y == 0 || x == w - 1 || y == h - 1 || m[i - 1] == 0 || m[i + 1] == 0 || m[i - w] == 0 || m[i + w] == 0;
-    if (!edge) continue;
-    mnx = min(mnx, x);
-    mny = min(mny, y);
-    mxx = max(mxx, x);
-    mxy = max(mxy, y);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mnx = min(mnx, __shfl_xor(mnx, o, 64));
-    mny = min(mny, __shfl_xor(mny, o, 64));
-    mxx = max(mxx, __shfl_xor(mxx, o, 64));
-    mxy = max(mxy, __shfl_xor(mxy, o, 64));
-  }
-  __shared__ int red[4][4];
-  const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    red[wv][0] = mnx;
-    red[wv][1] = mny;
-    red[wv][2] = mxx;
-    red[wv][3] = mxy;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; ++k) {
-      mnx = min(mnx, red[k][0]);
-      mny = min(mny, red[k][1]);
-      mxx = max(mxx, red[k][2]);
-      mxy = max(mxy, red[k][3]);
-    }
-    int* bb = sel.box + img * 4;
-    if (mxx >= 0) {
-      atomicMin(bb + 0, mnx);
-      atomicMin(bb + 1, mny);
-      atomicMax(bb + 2, mxx);
-      atomicMax(bb + 3, mxy);
-    }
-  }
-}
-
 __global__ void contour_sel_init_kernel(Sel sel, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   sel.best[i] = 0;
   sel.count[i] = 0;
-  sel.box[i * 4 + 0] = 0x7fffffff;
-  sel.box[i * 4 + 1] = 0x7fffffff;
-  sel.box[i * 4 + 2] = -1;
-  sel.box[i * 4 + 3] = -1;
 }
 
 // out[8] = area2 (>= 0), unit steps, diagonal steps, min x, min y, max x, max y, number of external contours
@@ -300,10 +274,11 @@ __global__ void contour_final_kernel(Acc acc, Sel sel, long long* __restrict__ o
   o[0] = (long long)(key >> 21);
   o[1] = (long long)(st & 0xffffffffull);
   o[2] = (long long)(st >> 32);
-  o[3] = sel.box[img * 4 + 0];
-  o[4] = sel.box[img * 4 + 1];
-  o[5] = sel.box[img * 4 + 2];
-  o[6] = sel.box[img * 4 + 3];
+  const int* bb = acc.box + ((int64_t)img * npix + r) * 4;
+  o[3] = bb[0];
+  o[4] = bb[1];
+  o[5] = bb[2];
+  o[6] = bb[3];
   o[7] = sel.count[img];
 }
 
@@ -315,11 +290,11 @@ inline unsigned grid_for(int64_t items) {
 
 }  // namespace
 
-// labels (npix + 1 ints) + area2 (8 B) + steps (8 B) per pixel and frame, + 32 B of selection scratch per frame
+// labels (npix + 1 ints) + area2 (8 B) + steps (8 B) + box (16 B) per pixel and frame, + 16 B of selection scratch per frame
 extern "C" int64_t lmx_contour_workspace_bytes(int n, int h, int w) {
   if (n <= 0 || h <= 0 || w <= 0) return 0;
   const int64_t npix = (int64_t)h * w;
-  return (int64_t)n * ((npix + 1) * 4 + npix * 16 + 32) + 256;
+  return (int64_t)n * ((npix + 1) * 4 + npix * 32 + 16) + 512;
 }
 
 extern "C" int lmx_k_contour_features(const uint8_t* mask, int n, int h, int w, int64_t* out, void* workspace, lmx_stream_t stream) {
@@ -338,24 +313,18 @@ extern "C" int lmx_k_contour_features(const uint8_t* mask, int n, int h, int w, 
   off += (int64_t)n * npix * 8;
   acc.steps = reinterpret_cast<unsigned long long*>(ws + off);
   off += (int64_t)n * npix * 8;
+  acc.box = reinterpret_cast<int*>(ws + off);
+  off += (int64_t)n * npix * 16;
   Sel sel;
   sel.best = reinterpret_cast<unsigned long long*>(ws + off);
   off += (int64_t)n * 8;
   sel.count = reinterpret_cast<int*>(ws + off);
-  off += (((int64_t)n * 4) + 15) & ~15ll;
-  sel.box = reinterpret_cast<int*>(ws + off);
-  LMX_HIP(hipMemsetAsync(acc.area2, 0, (size_t)n * npix * 16, st));  // area2 and steps are adjacent
   hipLaunchKernelGGL(contour_sel_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, sel, n);
   hipLaunchKernelGGL(cc_rows_kernel, dim3((unsigned)((int64_t)n * h)), dim3(256), 0, st, mask, L, h, w, npix);
   hipLaunchKernelGGL(cc_union_kernel, dim3(grid_for((int64_t)n * npix)), dim3(256), 0, st, mask, L, n, h, w, npix);
-  hipLaunchKernelGGL(cc_compress_kernel, dim3(grid_for((int64_t)n * (npix + 1))), dim3(256), 0, st, L, n, npix);
+  hipLaunchKernelGGL(cc_compress_kernel, dim3(grid_for((int64_t)n * (npix + 1))), dim3(256), 0, st, L, acc, n, npix);
   hipLaunchKernelGGL(contour_sum_kernel, dim3(grid_for((int64_t)n * npix)), dim3(256), 0, st, mask, L, acc, n, h, w, npix);
   hipLaunchKernelGGL(contour_select_kernel, dim3(grid_for((int64_t)n * npix)), dim3(256), 0, st, mask, L, acc, sel, n, w, npix);
-  {
-    int64_t gx = (npix + 255) / 256;
-    if (gx > 64) gx = 64;  // 64 blocks x 4 same-address atomics per frame
-    hipLaunchKernelGGL(contour_box_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, st, mask, L, sel, h, w, npix);
-  }
   hipLaunchKernelGGL(contour_final_kernel, dim3((n + 63) / 64), dim3(64), 0, st, acc, sel, reinterpret_cast<long long*>(out), n, npix);
   return lmx_launch_check("contour_final_kernel");
 }
