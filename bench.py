@@ -87,8 +87,10 @@ def pmc_traffic_by_class():
             cls = "gemm/hbm-bound"      # f32-output (residual-stream) instantiations
         elif "gemm" in name:
             cls = "gemm/mfma-bound"
+        elif "attn_kernel<2, true, false, true" in name or "attn_kernel<2, false, false, true" in name:
+            cls = "attention/mfma-bound"  # the LDS-DMA instantiations: long flat sequences (Hiera's global blocks)
         elif "attn" in name:
-            cls = "attention"
+            cls = "attention/hbm-bound"
         elif "ln_mlp" in name:
             cls = "fused ln+mlp"
         elif "layernorm" in name:
@@ -194,9 +196,16 @@ def main():
         out = {k: v for k, v in out.items() if k != "mask"}
         buf, _ = ldist.pack_records(out)
         if world > 1:
-            buf = ldist.gather_packed(buf, root=0)
-            if buf is None:
-                return
+            # ONE collective per step.  all_gather_into_tensor by default (RCCL's most travelled path; every rank then holds the
+            # records, rank 0 persists them); LMX_BENCH_GATHER=root uses the gather-to-rank-0 form the service uses
+            if os.environ.get("LMX_BENCH_GATHER") == "root":
+                buf = ldist.gather_packed(buf, root=0)
+                if buf is None:
+                    return
+            else:
+                buf = ldist.gather_packed(buf, root=None)
+                if rank != 0:
+                    return
         key = tuple(buf.shape)
         if key not in pinned:
             pinned[key] = torch.empty(buf.shape, dtype=torch.uint8).pin_memory()
