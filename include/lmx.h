@@ -73,6 +73,9 @@ typedef struct {
   int32_t res_rows;
 } lmx_gemm_desc;
 int lmx_k_gemm(const lmx_gemm_desc* d, lmx_stream_t stream);
+/* development hook (tools/gemm_sweep.py): force one tiling of the LDS-DMA GEMM for every following launch; v = 0 restores
+ * the launcher's per-shape choice, otherwise one of the letters documented at lmx_gemm2_launch (csrc/gemm2.hip) */
+void lmx_dbg_set_gemm2_variant(int v);
 
 /* ---- K11: LayerNorm over the last dim, f32 or f16 in -> f16 or f32 out ------------------------------
  * Replaces torch.nn.LayerNorm inside the ViT blocks (TF:models/dinov3_vit/modeling_dinov3_vit.py:400-445,

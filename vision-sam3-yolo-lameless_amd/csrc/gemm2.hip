@@ -369,12 +369,15 @@ using namespace lmx_gemm2;
 // called from lmx_k_gemm (gemm.hip) after validation, for a_mode 0.  LMX_GEMM2_VARIANT picks a tiling for experiments:
 //   A: 256x128x64, 3 slots (144 KB), 8 waves, 1 block/CU      B: 128x128x64, 2 slots (64 KB), 4 waves, 2 blocks/CU
 //   C: 256x128x32, 3 slots (72 KB), 8 waves, 2 blocks/CU      D: 256x128x32, 2 slots (48 KB), 8 waves, 3 blocks/CU
+static int g_variant = -1;  // -1: read LMX_GEMM2_VARIANT on first use; lmx_dbg_set_gemm2_variant overrides it (tools/gemm_sweep.py)
+extern "C" void lmx_dbg_set_gemm2_variant(int v) { g_variant = v; }
+
 int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
-  static int variant = -1;
-  if (variant < 0) {
+  if (g_variant < 0) {
     const char* e = getenv("LMX_GEMM2_VARIANT");
-    variant = e ? e[0] : 0;
+    g_variant = e ? e[0] : 0;
   }
+  const int variant = g_variant;
   if (d.a_mode == 1) {  // 3x3 convolution, Cin % 32 == 0 (checked by the caller)
     static int conv_small = -1;
     if (conv_small < 0) conv_small = getenv("LMX_GEMM2_CONV_SMALL") ? 1 : 0;
@@ -412,6 +415,11 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
       const double q256 = (double)tiles256 / (double)(((tiles256 + 255) / 256) * 256);
       if (d.K >= 448 && tiles256 >= 230 && q256 >= 0.75 && (d.K < 896 ? d.N % 256 == 0 : nfrac >= 0.85))
         return launch2<256, 256, 32, 3, 0, 1>(d, st);
+      // short K, N = 224 .. 1024 filling >= 85 % of its 256-wide tiles (Hiera's 224 / 448 / 672 / 896 with K = 112 .. 448):
+      // the plain 256 x 256 tiling wins 5-15 % over 256 x 128 (a third fewer L2->LDS bytes per flop; interleaved A/B in one
+      // process, profiles/r02_gemm_sweep_interleaved.txt); wider N (1344, 2688) loses with it
+      if (d.K <= 448 && d.N >= 224 && d.N <= 1024 && d.N % 256 != 0 && nfrac >= 0.85 && tiles256 >= 230 && q256 >= 0.75)
+        return launch2<256, 256, 32, 3, 0>(d, st);
       const int64_t tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128);
       return (d.K >= 1792 || tiles <= 256) ? launch2<256, 128, 64, 3, 0, 1>(d, st) : launch2<256, 128, 32, 3, 0>(d, st);
     }

@@ -45,6 +45,7 @@ SIGNATURES = {
     "lmx_last_error": (C.c_char_p, []),
     "lmx_device_count": (_I, []),
     "lmx_k_gemm": (_I, [C.POINTER(GemmDesc), _VP]),
+    "lmx_dbg_set_gemm2_variant": (None, [_I]),
     "lmx_k_pose_gather": (_I, [_VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _F, _F, _F, _F, _VP, _VP]),
     "lmx_k_pack_bits": (_I, [_VP, _I64, _I, _VP, _VP]),
     "lmx_k_ln_mlp": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _I, _F, _VP, _VP]),
