@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=150, help="frames of the synthetic clip per GPU per step (5 s @ 30 fps = 150)")
     ap.add_argument("--fps", type=int, default=30)
-    ap.add_argument("--sam-chunk", type=int, default=16, help="frames per SAM encoder pass (each pass runs on its own HIP stream)")
+    ap.add_argument("--sam-chunk", type=int, default=30, help="frames per SAM encoder pass (each pass runs on its own HIP stream; 150 = 5 x 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-schedule", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

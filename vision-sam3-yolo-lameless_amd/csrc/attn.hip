@@ -77,7 +77,10 @@ __device__ __forceinline__ half4_t lds_tr_read(const half_t* p) {
 // same, only wider.
 template <int QB, bool ONES, bool REL, bool DMA, int HDW>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, const Geo geo, const int nQT) {
-  constexpr int NSL = DMA ? 3 : 2;
+#ifndef LMX_ATTN_RING
+#define LMX_ATTN_RING 5  // LDS-DMA ring slots of 16 KB (K + V tile): 5 x 16 = 80 KB, two workgroups fill the CU's 160 KB exactly
+#endif
+  constexpr int NSL = DMA ? LMX_ATTN_RING : 2;
   constexpr int KS = HDW / 32;            // 32-wide k-steps of S = K . Q^T
   constexpr int NDB = HDW / 16;           // 16-wide blocks of the output head dim
   constexpr int RW = HDW <= 64 ? 64 : 128;  // halfs per LDS row
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
   // ---- LDS-DMA plan (DMA): wave w stages KB pieces 2w, 2w+1 of the K tile and of the V tile (8 rows x 128 B each);
   // the (chunk ^ row&7) swizzle goes on the per-lane SOURCE address, head-dim padding chunks and keys >= Tk fall outside
   // the descriptor (the row offset is in voffset, which the range check covers) and read as zeros.
-  constexpr int LA = 2, PT = 4;
+  constexpr int LA = DMA ? NSL - 1 : 2, PT = 4;  // key tiles in flight ahead of the one being consumed
   __amdgpu_buffer_rsrc_t k_rs, v_rs;
   unsigned kvo[2], vvo[2];
   if constexpr (DMA) {
@@ -254,13 +257,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
     if constexpr (DMA) {
       // tile `it` has landed once only this wave's DMAs of the next tile are outstanding (Q's loads are older; nothing else
       // is loaded from global memory in the loop)
-      if (it + 1 < ntile)
-        wait_vmcnt<PT>();
-      else
-        wait_vmcnt<0>();
+      // (with two tiles in flight a tile waited ~2000 cycles for its DMA - SQ_WAIT_ANY 42 % of the wave cycles - at ~1200
+      // cycles of MFMA + softmax per tile; four tiles ahead cover an L2 / HBM latency)
+      const int left = ntile - 1 - it;
+      wait_tiles<PT>(left < LA - 1 ? left : LA - 1);
       __builtin_amdgcn_s_barrier();
-      if (it + LA < ntile) issue(it + LA, (it + LA) % 3);
-      buf = it % 3;
+      if (it + LA < ntile) issue(it + LA, (it + LA) % NSL);
+      buf = it % NSL;
     } else {
       buf = it & 1;
       if (it + 1 < ntile) load_tile(t0 + 64);

@@ -32,8 +32,9 @@ class FusedExtractor:
         self.serial = bool(os.environ.get("LMX_SERIAL"))  # True: every launch on the caller's stream
         # HIP streams one step may keep in flight (>= 3): YOLO, DINO and up to four SAM passes.  Round 1 capped this at 4 because
         # more SAM passes in flight showed wrong mask pixels; round 2 traced that to an instruction form the build now forbids
-        # (DESIGN.md section 6), so the cap is a performance setting again: 6 measures +3.8 % over 4.
-        self.max_streams = int(os.environ.get("LMX_MAX_STREAMS", "6"))
+        # (DESIGN.md section 6), so the cap is a performance setting again: 6 measures +3.8 % over 4; 7 = YOLO, DINO and the
+        # five SAM passes of 30 frames of a 150-frame clip.
+        self.max_streams = int(os.environ.get("LMX_MAX_STREAMS", "7"))
         self.stream_layout = os.environ.get("LMX_STREAM_LAYOUT", "lanes")
         ycfg = yolo.YoloConfig(yolo_scale)
         bn = yolo_bn or os.path.join(GOLDEN, f"yolov8{yolo_scale}_bn_w{weight_seeds[0]}.npz")
@@ -51,7 +52,7 @@ class FusedExtractor:
         self = cls.__new__(cls)
         self.device = detector.device
         self.serial = bool(os.environ.get("LMX_SERIAL"))
-        self.max_streams = int(os.environ.get("LMX_MAX_STREAMS", "6"))
+        self.max_streams = int(os.environ.get("LMX_MAX_STREAMS", "7"))
         self.stream_layout = os.environ.get("LMX_STREAM_LAYOUT", "lanes")
         self.yolo, self.sam, self.decoder, self.dino = detector, sam_encoder, mask_decoder, embedder
         return self
