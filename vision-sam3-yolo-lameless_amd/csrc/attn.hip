@@ -65,6 +65,23 @@ __device__ __forceinline__ half4_t lds_tr_read(const half_t* p) {
   return h;
 }
 
+// LDS reads at `base + compile-time offset` with the base made opaque to the optimiser: hipcc's loop strength reduction
+// otherwise rewrites the ring-slot addressing into bases with NEGATIVE constant parts, which cannot be DS offset immediates,
+// and spends ~45 integer VALU per key tile on addresses (a quarter of the VALU work of a tile that is VALU-bound).
+typedef __attribute__((address_space(3))) const half8_t* lds_h8_cptr;
+__device__ __forceinline__ unsigned lds_addr(const half_t* p) {
+  unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const half_t*)p;
+  asm volatile("" : "+v"(a));
+  return a;
+}
+__device__ __forceinline__ half8_t lds_read8(unsigned base, int byte_off) { return *(lds_h8_cptr)(uintptr_t)(base + (unsigned)byte_off); }
+__device__ __forceinline__ half4_t lds_tr_read_at(unsigned base, int byte_off) {
+  const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_ptr)(uintptr_t)(base + (unsigned)byte_off));
+  half4_t h;
+  __builtin_memcpy(&h, &v, 8);
+  return h;
+}
+
 // QB: 16-query blocks per wave.  ONES: head dim <= 56, so V's (zero) column 63 is set to 1 and the PV MFMA itself
 // accumulates the softmax normaliser in O[:,63] — no row-sum instructions at all.
 // REL: SAM v1 decomposed relative-position bias read from the per-query tables of relpos_tables_kernel.
@@ -78,7 +95,7 @@ __device__ __forceinline__ half4_t lds_tr_read(const half_t* p) {
 template <int QB, bool ONES, bool REL, bool DMA, int HDW>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, const Geo geo, const int nQT) {
 #ifndef LMX_ATTN_RING
-#define LMX_ATTN_RING 5  // LDS-DMA ring slots of 16 KB (K + V tile): 5 x 16 = 80 KB, two workgroups fill the CU's 160 KB exactly
+#define LMX_ATTN_RING 3  // LDS-DMA ring slots of 16 KB (K + V tile).  Measured: 3 slots 586 TFLOP/s, 4 and 5 slots 480-530 (profiles/r02_ab_attn_ring.txt)
 #endif
   constexpr int NSL = DMA ? LMX_ATTN_RING : 2;
   constexpr int KS = HDW / 32;            // 32-wide k-steps of S = K . Q^T
@@ -248,6 +265,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
     store_tile(0);
     __syncthreads();
   }
+  // Loop-invariant lane parts of the LDS fragment addresses (in halfs), so that a tile pays one add per base for the ring
+  // slot and the rest are instruction-offset immediates (hipcc otherwise re-derives ~45 integer VALU per tile from `buf`):
+  // K fragment of k-step ks, key block kb: k_lane[ks] + kb * 16 * RW;  V^T fragment of d-block db, k-step ks: v_lane[db] + ks * 32 * RW (+ 16 * RW)
+  int k_lane[KS], v_lane[NDB];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_lane[ks] = fr * RW + ((((ks << 2) + fg) ^ (fr & (CPR - 1))) << 3);
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) {
+    const int chunk = db * 2 + (p4 >> 1), rl = fg * 4 + q4;  // (rl + 32 ks (+ 16)) & (CPR - 1) == rl & (CPR - 1): CPR <= 16
+    v_lane[db] = rl * RW + ((chunk ^ (rl & (CPR - 1))) << 3) + (p4 & 1) * 4;
+  }
   // The body is instantiated twice: full tiles carry NO masking code at all (hipcc otherwise if-converts the
   // wave-uniform `partial` test into a compare+select per score element: ~60 VALU per tile), the last tile masks.
   auto tile_body = [&](const int it, auto mask_tag) {
@@ -257,8 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
     if constexpr (DMA) {
       // tile `it` has landed once only this wave's DMAs of the next tile are outstanding (Q's loads are older; nothing else
       // is loaded from global memory in the loop)
-      // (with two tiles in flight a tile waited ~2000 cycles for its DMA - SQ_WAIT_ANY 42 % of the wave cycles - at ~1200
-      // cycles of MFMA + softmax per tile; four tiles ahead cover an L2 / HBM latency)
+      // (a deeper ring does not help: DMA latency is not what the waves wait for — 4 / 5 slots measured 10-20 % slower)
       const int left = ntile - 1 - it;
       wait_tiles<PT>(left < LA - 1 ? left : LA - 1);
       __builtin_amdgcn_s_barrier();
@@ -269,6 +296,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
       if (it + 1 < ntile) load_tile(t0 + 64);
     }
 
+    // one base per (k-step | d-block) and ring slot; everything else below is an instruction-offset immediate
+    unsigned kbase[KS], vbase[NDB];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kbase[ks] = lds_addr(&Ks[buf][k_lane[ks]]);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) vbase[db] = lds_addr(&Vs[buf][v_lane[db]]);
+
     // ---- S^T = K . Q^T  (raw, unscaled)
     f32x4 sacc[QB][4];
 #pragma unroll
@@ -277,10 +311,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
       for (int kb = 0; kb < 4; ++kb) sacc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const int coff = (((ks << 2) + fg) ^ (fr & (CPR - 1))) << 3;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[buf][(kb * 16 + fr) * RW + coff]);
+        const half8_t kf = lds_read8(kbase[ks], kb * 16 * RW * 2);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
           sacc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qb][ks], sacc[qb][kb], 0, 0, 0);
@@ -361,10 +394,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int db = 0; db < NDB; ++db) {
-        const int chunk = db * 2 + (p4 >> 1);
-        const int r0 = ks * 32 + fg * 4 + q4, r1 = r0 + 16;
-        const half4_t lo = lds_tr_read(&Vs[buf][r0 * RW + ((chunk ^ (r0 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
-        const half4_t hi = lds_tr_read(&Vs[buf][r1 * RW + ((chunk ^ (r1 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
+        const half4_t lo = lds_tr_read_at(vbase[db], ks * 32 * RW * 2);
+        const half4_t hi = lds_tr_read_at(vbase[db], (ks * 32 + 16) * RW * 2);
         half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if (DMA && ONES && db == 3) {  // row d = 63 of V^T (lanes fr == 15) is the ones row: the staged tile holds zeros there
           const half_t one = (half_t)1.0f;
