@@ -83,6 +83,9 @@ def pmc_traffic_by_class():
         rows = json.load(f)
     acc = {}
     for name, r in rows.items():
+        # the counters are per KERNEL NAME, the classes per launch (arithmetic intensity): the f32-output (residual-stream)
+        # GEMM instantiations stand for the HBM-bound GEMM class, the f16-output ones for the MFMA-bound class — close, not
+        # identical sets of launches (profiles/r02_pmc_summary.txt has the per-kernel rows)
         if "gemm2_kernel<1" in name or "gemm_kernel" in name and ", 1>" in name:
             cls = "gemm/hbm-bound"      # f32-output (residual-stream) instantiations
         elif "gemm" in name:
