@@ -402,6 +402,7 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     case 'V': return launch2<256, 128, 32, 4, 0, 1>(d, st);  // staggered, 4 x 24 KB ring
     case 'W': return launch2<256, 256, 32, 4, 0, 1>(d, st);  // staggered 256x256, 16 waves, 4 x 32 KB ring
     case 'Y': return launch2<256, 256, 32, 3, 0, 1>(d, st);  // staggered 256x256, 3 x 32 KB ring
+    case 'Z': return launch2<256, 256, 64, 2, 0>(d, st);     // 256x256x64, 2 x 64 KB: half the barriers, 128-byte DMA row pieces
     default: {
       // measured on the model shapes (profiles/r01_gemm_variants.txt, r01_gemm_staggered_variants.txt): with K < ~1.8k the
       // per-tile prologue/epilogue dominates and two co-resident workgroups (C) hide it; long-K problems, and problems with
@@ -413,8 +414,12 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
       const int64_t nt256 = (d.N + 255) / 256, tiles256 = (int64_t)((d.M + 255) / 256) * nt256;
       const double nfrac = (double)d.N / (double)(nt256 * 256);
       const double q256 = (double)tiles256 / (double)(((tiles256 + 255) / 256) * 256);
-      if (d.K >= 448 && tiles256 >= 230 && q256 >= 0.75 && (d.K < 896 ? d.N % 256 == 0 : nfrac >= 0.85))
+      if (d.K >= 448 && tiles256 >= 230 && q256 >= 0.75 && (d.K < 896 ? d.N % 256 == 0 : nfrac >= 0.85)) {
+        // long K: 64-deep k-tiles on a 2 x 64 KB ring (half the barriers, 128-byte DMA row pieces) measure 4-5 % ahead of the
+        // staggered 32-deep schedule (fc2 of Hiera stages 3-4; profiles/r02_gemm_sweep_interleaved.txt, variant Z)
+        if (d.K >= 1792) return launch2<256, 256, 64, 2, 0>(d, st);
         return launch2<256, 256, 32, 3, 0, 1>(d, st);
+      }
       // short K, N = 224 .. 1024 filling >= 85 % of its 256-wide tiles (Hiera's 224 / 448 / 672 / 896 with K = 112 .. 448):
       // the plain 256 x 256 tiling wins 5-15 % over 256 x 128 (a third fewer L2->LDS bytes per flop; interleaved A/B in one
       // process, profiles/r02_gemm_sweep_interleaved.txt); wider N (1344, 2688) loses with it
