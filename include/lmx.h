@@ -108,7 +108,10 @@ int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const float* beta, c
  *                     padding take K = pad_k[h], V = pad_v[h] (= the qkv bias: what Linear(0) yields).
  *                     Queries use the same map on a grid subsampled by q_stride (1, or 2 for Hiera Q-pool):
  *                     grid [Gh/q][Gw/q]... see DESIGN.md §attention.
- * hd%8==0, hd<=64.
+ * hd % 8 == 0, hd <= 96 (head dims up to 64 use 64-half LDS rows; 72..96 — SAM ViT-H's 80 — the 128-half class).
+ * Three kernels behind the one entry point, chosen from the shape: tiles of 64 keys with an online softmax (any length;
+ * LDS-DMA ring for long flat sequences), whole-sequence tiles for 128 < Tk <= 208 (single-pass softmax), one wave per
+ * item for Tq, Tk <= 16.
  */
 typedef struct {
   const void* Q; const void* K; const void* V; void* O;
