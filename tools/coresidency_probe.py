@@ -2,7 +2,9 @@
 in a loop on one stream, a background kernel in a loop on three other streams, nothing else.  Counts the launches whose
 mask differs from the idle reference.
 
-  LMX_DBG_MASK=1 python tools/coresidency_probe.py {none|gemm|ln|attn}     (LMX_GEMM_V1=1: register-staged GEMM)"""
+  LMX_LIB=$PWD/vision-sam3-yolo-lameless_amd/lmx/liblmx_dbg.so LMX_DBG_MASK=1 python tools/coresidency_probe.py {none|gemm|ln|attn}
+(the DBG variants exist in the development build only: make -C vision-sam3-yolo-lameless_amd/csrc dbg; liblmx_dbg_noslp.so is
+the same without hipcc's SLP vectoriser and is clean — round 2's decisive A/B, tools/defect_round2.sh)"""
 import os
 import sys
 

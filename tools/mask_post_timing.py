@@ -1,4 +1,5 @@
-"""Development aid: time lmx_k_mask_post (16 frames, 256^2 logits -> 1080p masks) under the current LMX_DBG_MASK setting."""
+"""Development aid: time lmx_k_mask_post (16 frames, 256^2 logits -> 1080p masks) under the current LMX_DBG_MASK setting
+(variants other than 0 need LMX_LIB=.../liblmx_dbg.so: make -C vision-sam3-yolo-lameless_amd/csrc dbg)."""
 import os
 import sys
 

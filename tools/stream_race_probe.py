@@ -1,5 +1,8 @@
 """Development aid: is the mask a 64-frame multi-stream step produces equal to mask_post recomputed afterwards (everything
-idle) from the very logits that step left behind?  DESIGN.md section 6 tells the story.
+idle) from the very logits that step left behind?  DESIGN.md section 6 tells the story.  Round 2: the LMX_DBG_MASK variants
+live in the development build only (make -C vision-sam3-yolo-lameless_amd/csrc dbg; prefix the commands below with
+LMX_LIB=$PWD/vision-sam3-yolo-lameless_amd/lmx/liblmx_dbg.so); the cause turned out to be the ARITHMETIC hipcc's SLP
+vectoriser generated beside plain loads, not the loads (tools/pk_hazard_probe2.hip, tools/defect_round2.sh).
 
   LMX_DBG_MASK=1 LMX_STREAM_LAYOUT=rr LMX_MAX_STREAMS=6 python tools/stream_race_probe.py   # plain loads: differs
   LMX_DBG_MASK=2 ...                                                                        # + ordering counters
