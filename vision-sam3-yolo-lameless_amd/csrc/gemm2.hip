@@ -17,9 +17,17 @@
 //     1024 MFMA cycles per SIMD.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // (no anonymous namespace here: hipcc does not emit the host stub of an internal-linkage kernel template that is only
 // instantiated from another template — the library then fails to load with an undefined symbol)
+#ifdef LMX_DBG_TIMELINE
+__device__ unsigned long long lmx_tl[8 * 16384];  // per tile: hw id, xcc id, start, main loop end, end (100 MHz clock), bid
+extern "C" int lmx_dbg_get_timeline(void* host, int64_t bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lmx_tl), bytes); }
+#define TL(i, v) if (threadIdx.x == 0 && swz < 16384) lmx_tl[swz * 8 + (i)] = (v)
+#else
+#define TL(i, v)
+#endif
 namespace lmx_gemm2 {
 
 __device__ __forceinline__ float act_apply(float v, int act) { return lmx_act(v, act); }
@@ -34,8 +42,9 @@ __device__ __forceinline__ float act_apply(float v, int act) { return lmx_act(v,
 // waves per SIMD the register allocation must allow: two workgroups per CU when the ring leaves room for them.  Stated as
 // a thread bound (waves x 256 threads = that many waves on each of the 4 SIMDs) rather than as a minimum-occupancy hint: the
 // hint makes hipcc schedule up to the cap and spill a few registers in the 128-register kernels.
+constexpr int smem_bytes(int BM, int BN, int BK, int NSTAGE) { return NSTAGE * (BM + BN) * BK * 2 + 2 * BN * 4; }  // ring + bias/scale
 constexpr int waves_per_simd(int BM, int BN, int BK, int NSTAGE) {
-  const int smem = NSTAGE * (BM + BN) * BK * 2, nwave = (BM / 64) * (BN / 64);
+  const int smem = smem_bytes(BM, BN, BK, NSTAGE), nwave = (BM / 64) * (BN / 64);
   const int wps = (smem <= 80 * 1024 ? 2 : 1) * nwave / 4;
   return wps < 1 ? 1 : wps;
 }
@@ -68,6 +77,10 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   const int swz = base + li;
   const int mt = swz / NT, nt = swz - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
+  TL(0, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));
+  TL(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));
+  TL(2, wall_clock64());
+  TL(5, (unsigned long long)bid);
 
   // buffer descriptors over this block's row panels: the hardware range check returns 0 beyond the last valid byte
   const int hw_out = (AMODE == 1) ? p.Ho * p.Wo : 1;
@@ -149,6 +162,16 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // bias and LayerScale of this tile's BN channels: requested now, parked in LDS (behind the ring) after the main loop,
+  // read per fragment by the epilogue — their latency hides behind the k-loop at the price of two registers
+  float* bl = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);  // [2][BN]
+  // (the convolution variant has no registers to spare across its k-loop and asks after it)
+  float bias_v = 0.f, scale_v = 1.f;
+  if (AMODE == 0 && tid < BN && n0 + tid < p.N) {
+    if (p.bias) bias_v = p.bias[n0 + tid];
+    if (p.scale) scale_v = p.scale[n0 + tid];
+  }
 
 #pragma unroll
   for (int t = 0; t < LA; ++t)
@@ -238,107 +261,150 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   // 64 x 64 tile through its own slice of the (now idle) staging LDS and writes whole 128-/256-byte row segments with
   // 16-byte lane stores; the residual is read in the same coalesced shape.  bias / activation / LayerScale are applied
   // in registers on the way in.
-  __builtin_amdgcn_s_barrier();  // every wave is done reading the last k-tile
+  if (AMODE == 1 && tid < BN && n0 + tid < p.N) {
+    if (p.bias) bias_v = p.bias[n0 + tid];
+    if (p.scale) scale_v = p.scale[n0 + tid];
+  }
+  if (tid < BN) {
+    bl[tid] = bias_v;
+    bl[BN + tid] = scale_v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a raw s_barrier does not wait for this wave's LDS writes
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the last k-tile; bias / scale are in LDS
+  TL(3, wall_clock64());
 #ifdef LMX_DBG_NOEPI
   if (p.M > 0 && acc[0][0][0] != 12345.f) continue;  // development probe: no epilogue
 #endif
-  const int act = p.act;
   // a large f16 output whose rows are whole 128-byte lines streams past L2 (`nt`): written back normally it evicts the A
   // and W panels the co-resident tiles are re-reading (measured: fc1 of Hiera stage 3 561 -> 628 TFLOP/s, stage 2 387 -> 549;
   // ragged rows and the in-place f32 residual update lose with nt and keep the default policy)
   const bool nt_out = nt_ok && OUT_DT == LMX_F16 && ((p.ldc * 2) & 127) == 0 && (int64_t)p.M * p.N >= (16ll << 20);
   char* my = smem + wave * 4608;  // 32 rows x 144 B (f16) or 16 rows x 272 B (f32) per pass
-  f32x4 bia[4], scl[4];
+  // The activation and the presence of a LayerScale vector are compile-time inside the body (one uniform switch per tile
+  // instead of one per fragment: the independent activation chains of a pass interleave, no branch separates them).
+  auto epilogue = [&](auto act_c, auto scale_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    constexpr bool SCALE = decltype(scale_c)::value;
+    // (bias / scale are re-read from LDS per fragment: held in registers they are 32 live VGPRs on top of the 64 of
+    // the accumulators in kernels capped at 128)
+    const float* blj = bl + wn * 64 + fq * 4;
+    auto finish = [&](f32x4 v, int j) -> f32x4 {
+      v += *reinterpret_cast<const f32x4*>(blj + j * 16);
+      if constexpr (ACT == LMX_ACT_GELU) {  // two values per v_pk_fma_f32 chain
+        const f32x2 g0 = gelu_pk(f32x2{v[0], v[1]}), g1 = gelu_pk(f32x2{v[2], v[3]});
+        v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+      } else if constexpr (ACT != LMX_ACT_NONE) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wn * 64 + j * 16 + fq * 4;
-    bia[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    scl[j] = (p.scale && n < p.N) ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-  }
-  if (OUT_DT == LMX_F16) {
-    half_t* t16 = reinterpret_cast<half_t*>(my);
-    constexpr int RS = 72;  // halfs per LDS row: 64 + 8 (16-byte pad keeps ds_read_b128 aligned and spreads banks)
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
+      }
+      if constexpr (SCALE) v *= *reinterpret_cast<const f32x4*>(blj + BN + j * 16);
+      return v;
+    };
+    if constexpr (OUT_DT == LMX_F16) {
+      half_t* t16 = reinterpret_cast<half_t*>(my);
+      constexpr int RS = 72;  // halfs per LDS row: 64 + 8 (16-byte pad keeps ds_read_b128 aligned and spreads banks)
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+      for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 v = acc[pass * 2 + ii][j] + bia[j];
-          if (act == LMX_ACT_GELU) {  // two values per v_pk_fma_f32 chain
-            const f32x2 g0 = gelu_pk(f32x2{v[0], v[1]}), g1 = gelu_pk(f32x2{v[2], v[3]});
-            v = f32x4{g0[0], g0[1], g1[0], g1[1]};
-          } else if (act != LMX_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 v = finish(acc[pass * 2 + ii][j], j);
+            const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4_t*>(t16 + (ii * 16 + frow) * RS + j * 16 + fq * 4) = o;
           }
-          v *= scl[j];
-          const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *reinterpret_cast<half4_t*>(t16 + (ii * 16 + frow) * RS + j * 16 + fq * 4) = o;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+          half8_t o = *reinterpret_cast<const half8_t*>(t16 + row * RS + c8 * 8);
+          const int m = m0 + wm * 64 + pass * 32 + row;
+          const int n = n0 + wn * 64 + c8 * 8;
+          if (m < p.M && n < p.N) {
+            if (p.res) {
+              const int mr = p.res_rows > 0 ? m % p.res_rows : m;
+              const half8_t rr = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.res) + (int64_t)mr * p.ldr + n);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
+            }
+            half8_t* dst = reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n);
+            if (nt_out)  // (asm: hipcc merges a __builtin_nontemporal_store with the plain store of the other branch and drops nt)
+              asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(o) : "memory");
+            else
+              *dst = o;
+          }
         }
+      }
+    } else {
+      float* t32 = reinterpret_cast<float*>(my);
+      constexpr int RS = 68;  // floats per LDS row: 64 + 4
+      // (requesting the residual rows one or two passes ahead measured 6-15 % SLOWER on the model's f32 shapes: the tile's
+      // read-modify-write of the residual stream runs at the memory system's mixed read/write rate with one pass in
+      // flight already — all 256 CUs reach their epilogues together and move 8 TB/s between them while it lasts;
+      // profiles/r02_gemm_epilogue.txt)
+      const int lrow = lane >> 4, c16 = lane & 15;
+      const int n = n0 + wn * 64 + c16 * 4;
+      const bool has_res = p.res != nullptr;
+      f32x4 rr[4];
+      auto load_res = [&](int pass) {
+        f32x4* d = rr;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + (lane >> 3), c8 = lane & 7;
-        half8_t o = *reinterpret_cast<const half8_t*>(t16 + row * RS + c8 * 8);
-        const int m = m0 + wm * 64 + pass * 32 + row;
-        const int n = n0 + wn * 64 + c8 * 8;
-        if (m < p.M && n < p.N) {
-          if (p.res) {
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + wm * 64 + pass * 16 + it * 4 + lrow;
+          d[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (has_res && m < p.M && n < p.N) {
             const int mr = p.res_rows > 0 ? m % p.res_rows : m;
-            const half8_t rr = *reinterpret_cast<const half8_t*>(reinterpret_cast<const half_t*>(p.res) + (int64_t)mr * p.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rr[e]);
+            d[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)mr * p.ldr + n);
           }
-          half8_t* dst = reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (int64_t)m * p.ldc + n);
-          if (nt_out)  // (asm: hipcc merges a __builtin_nontemporal_store with the plain store of the other branch and drops nt)
-            asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(o) : "memory");
-          else
-            *dst = o;
+        }
+      };
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        load_res(pass);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(t32 + frow * RS + j * 16 + fq * 4) = finish(acc[pass][j], j);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 4 + lrow;
+          f32x4 o = *reinterpret_cast<const f32x4*>(t32 + row * RS + c16 * 4);
+          const int m = m0 + wm * 64 + pass * 16 + row;
+          if (m < p.M && n < p.N) {
+            if (has_res) o += rr[it];
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
+          }
         }
       }
     }
-  } else {
-    float* t32 = reinterpret_cast<float*>(my);
-    constexpr int RS = 68;  // floats per LDS row: 64 + 4
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 v = acc[pass][j] + bia[j];
-        if (act == LMX_ACT_GELU) {
-          const f32x2 g0 = gelu_pk(f32x2{v[0], v[1]}), g1 = gelu_pk(f32x2{v[2], v[3]});
-          v = f32x4{g0[0], g0[1], g1[0], g1[1]};
-        } else if (act != LMX_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
-        }
-        v *= scl[j];
-        *reinterpret_cast<f32x4*>(t32 + frow * RS + j * 16 + fq * 4) = v;
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 4 + (lane >> 4), c16 = lane & 15;
-        f32x4 o = *reinterpret_cast<const f32x4*>(t32 + row * RS + c16 * 4);
-        const int m = m0 + wm * 64 + pass * 16 + row;
-        const int n = n0 + wn * 64 + c16 * 4;
-        if (m < p.M && n < p.N) {
-          if (p.res) {
-            const int mr = p.res_rows > 0 ? m % p.res_rows : m;
-            o += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (int64_t)mr * p.ldr + n);
-          }
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
-        }
-      }
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    const int act = p.act;
+    if (p.scale) {
+      if (act == LMX_ACT_NONE) epilogue(std::integral_constant<int, LMX_ACT_NONE>{}, T{});
+      else if (act == LMX_ACT_SILU) epilogue(std::integral_constant<int, LMX_ACT_SILU>{}, T{});
+      else if (act == LMX_ACT_GELU) epilogue(std::integral_constant<int, LMX_ACT_GELU>{}, T{});
+      else epilogue(std::integral_constant<int, LMX_ACT_RELU>{}, T{});
+    } else {
+      if (act == LMX_ACT_NONE) epilogue(std::integral_constant<int, LMX_ACT_NONE>{}, F{});
+      else if (act == LMX_ACT_SILU) epilogue(std::integral_constant<int, LMX_ACT_SILU>{}, F{});
+      else if (act == LMX_ACT_GELU) epilogue(std::integral_constant<int, LMX_ACT_GELU>{}, F{});
+      else epilogue(std::integral_constant<int, LMX_ACT_RELU>{}, F{});
     }
   }
+  TL(6, wall_clock64());
   __builtin_amdgcn_s_barrier();  // the staging slices are ring memory: nobody restages it before every wave has read its slice
+  TL(4, wall_clock64());
+#ifdef LMX_DBG_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TL(7, wall_clock64());
+#endif
   }  // tile loop
 }
 
 template <int BM, int BN, int BK, int NSTAGE, int AMODE, int STAG = 0>
 int launch2(const lmx_gemm_desc& d, hipStream_t st) {
   const int MT = (d.M + BM - 1) / BM, NT = (d.N + BN - 1) / BN;
-  const size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;  // >= NWAVE * 4608 B of epilogue staging for every variant
+  const size_t smem = smem_bytes(BM, BN, BK, NSTAGE);  // the ring is >= NWAVE * 4608 B of epilogue staging for every variant
   static bool attr_set = false;
   if (!attr_set) {
     LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<LMX_F16, BM, BN, BK, NSTAGE, AMODE, STAG>),
@@ -393,7 +459,6 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     case 'D': return launch2<256, 128, 32, 2, 0>(d, st);
     case 'E': return launch2<256, 256, 32, 3, 0>(d, st);  // 16 waves, 96 KB, 1 block/CU: half the L2->LDS bytes per flop
     case 'F': return launch2<256, 256, 32, 4, 0>(d, st);  // ... 128 KB ring: three k-tiles in flight
-    case 'G': return launch2<256, 256, 32, 5, 0>(d, st);  // ... 160 KB ring: four k-tiles in flight
     case 'H': return launch2<128, 128, 32, 2, 0>(d, st);  // 4 waves, 32 KB: up to 4 blocks/CU for short-K (HBM-bound) shapes
     case 'I': return launch2<128, 128, 32, 3, 0>(d, st);  // 4 waves, 48 KB: 3 blocks/CU
     case 'S': return launch2<256, 128, 32, 6, 0, 1>(d, st);  // staggered wave groups, 6 x 24 KB ring, 1 block/CU

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
     }
   }
 
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // b1s: a raw s_barrier does not wait for this wave's LDS writes
   for (int c = 0; c < NCH; ++c) {
     // chunk c has landed once only this wave's DMAs of the (at most LA-1) younger chunks are outstanding; everything the
     // prologue loaded from global memory is consumed by now, and nothing else is loaded from global memory inside the
