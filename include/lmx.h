@@ -281,6 +281,17 @@ int lmx_k_contour_features(const uint8_t* mask, int n, int h, int w, int64_t* ou
  * perimeter is unit steps + diagonal steps * sqrt 2 in both). */
 int lmx_h_mask_features(const uint8_t* mask_host, int h, int w, double* out_host);
 
+/* ---- HOST functions of the tracking service (all pointers are HOST memory) -------------------
+ * The association arithmetic of services/tracking-service/app/tracker/matching.py, the consumer of pipeline.yolo /
+ * pipeline.dinov3: per frame a detections x tracks IoU matrix and one minimum-cost assignment on it (tens of boxes,
+ * sequential per frame: host code in the reference, host code here; lmx/services/tracking.py is the caller).
+ * lmx_h_iou_matrix: iou_batch (matching.py:12-44): a [n][4], b [m][4] xyxy boxes -> out [n][m] = inter / (union + 1e-6).
+ * lmx_h_assign: linear_assignment (matching.py:69-101) = lap.lapjv(cost, extend_cost=True, cost_limit=100000) on a finite
+ *   cost [n][m]: the minimum-cost assignment matching min(n, m) pairs; row_to_col [n] / col_to_row [m] hold the partner or -1.
+ *   (lap is absent: parity unpinned; optimality is tested against scipy.optimize.linear_sum_assignment.) */
+int lmx_h_iou_matrix(const double* a, int n, const double* b, int m, double* out);
+int lmx_h_assign(const double* cost, int n, int m, int* row_to_col, int* col_to_row);
+
 #ifdef __cplusplus
 }
 #endif

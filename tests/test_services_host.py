@@ -240,6 +240,27 @@ def test_fused_service_equals_the_three_services(tmp_path, monkeypatch, fps, n_f
     assert any(sg["mask_available"] for sg in sam["segmentations"]) and not all(sg["mask_available"] for sg in sam["segmentations"])
 
 
+def test_tracking_service_consumes_what_the_fused_service_publishes(tmp_path):
+    """video.preprocessed -> (fused: pipeline.yolo, pipeline.sam3, pipeline.dinov3) -> tracking.complete -> tracking.reid.match on
+    one bus: the tracker reads the YOLO JSON's per-frame containers and the DINO JSON's canonical_frames as they are written."""
+    from lmx.services import tracking as TR
+
+    path = _clip(tmp_path, 120, 30.0)
+    per_frame = (lambda fid: [([4 + fid // 6, 6, 40 + fid // 6, 40], 0.9, 19), ([50, 2, 62, 12], 0.3, 0)])
+    bus = R.InProcessBus()
+    _, _, _, fused, _ = _three_and_fused(tmp_path, "f", bus, per_frame)
+    trk = TR.TrackingService(bus, TR.MemoryIdentityStore(), _cfg(), results_dir=str(tmp_path / "tracking"))
+    _run(fused.start())
+    _run(trk.start())
+    _run(bus.publish("video.preprocessed", {"video_id": "z", "processed_path": str(path), "filename": "z.mp4"}))
+    assert [p[0] for p in bus.published] == ["video.preprocessed", "pipeline.yolo", "tracking.complete", "pipeline.sam3", "pipeline.dinov3",
+                                            "tracking.reid.match"]
+    res = json.load(open(tmp_path / "tracking" / "z_tracking.json"))
+    assert res["total_tracks"] == 1 and res["track_summaries"][0]["total_frames"] == 8 and res["reid_complete"] is True
+    assert [r["frame"] for r in res["frame_tracks"]] == [30, 45, 60, 75, 90, 105] and {r["track_id"] for r in res["frame_tracks"]} == {0}
+    assert res["reid_results"][0]["cow_id"] == "COW-0001" and res["statistics"]["confirmed"] == 1
+
+
 def test_clip_streams_and_keeps_only_sampled_frames(tmp_path, monkeypatch):
     """A video file is read like the reference's cap.read() loop: one decoded frame alive at a time, only sampled frames kept
     (the round-1 reader stacked every frame of the clip: 56 GB for five minutes of 1080p)."""

@@ -71,6 +71,8 @@ SIGNATURES = {
     "lmx_k_cast_f32_f16": (_I, [_VP, _I64, _VP, _I64, _I64, _I, _VP]),
     "lmx_k_add_bcast": (_I, [_VP, _I, _I64, _VP, _I64, _I, _VP, _I, _I64, _I64, _I, _VP]),
     "lmx_h_mask_features": (_I, [_VP, _I, _I, _VP]),
+    "lmx_h_iou_matrix": (_I, [_VP, _I, _VP, _I, _VP]),
+    "lmx_h_assign": (_I, [_VP, _I, _I, _VP, _VP]),
     "lmx_contour_workspace_bytes": (_I64, [_I, _I, _I]),
     "lmx_k_contour_features": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
     "lmx_k_prompt_box": (_I, [_VP, _I64, _VP, _I, _D, _D, _F, _VP, _VP, _I, _VP]),
