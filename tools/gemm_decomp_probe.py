@@ -28,6 +28,15 @@ for M, N, Kd, f32, act, res in SHAPES:
     r = torch.randn(M, N, device=dev, generator=g).to(dt) if res else None
     b = torch.randn(N, device=dev, generator=g)
     best = {v: 1e30 for v in VARS}
+    ref, same = None, {}
+    for v in VARS:  # every tiling must produce the same bits (one k-order, one epilogue rounding sequence)
+        lib.lmx_dbg_set_gemm2_variant(0 if v == "default" else ord(v))
+        o.zero_()
+        K.gemm(a, w, bias=b, act=act, res=r, out=o)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = o.clone()
+        same[v] = bool(torch.equal(o, ref))
     for rnd in range(3):
         for v in VARS:
             lib.lmx_dbg_set_gemm2_variant(0 if v == "default" else ord(v))
@@ -41,6 +50,7 @@ for M, N, Kd, f32, act, res in SHAPES:
             torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) * 1000.0 / 6)
     fl = 2.0 * M * N * Kd
-    print(f"M={M} N={N} K={Kd} f32={f32} act={act} res={res}: " + "  ".join(f"{v}:{u:.1f}us/{fl / u / 1e6:.0f}TF" for v, u in best.items()), flush=True)
+    print(f"M={M} N={N} K={Kd} f32={f32} act={act} res={res}: " + "  ".join(f"{v}:{u:.1f}us/{fl / u / 1e6:.0f}TF" for v, u in best.items()) +
+          ("" if all(same.values()) else f"  BITS DIFFER: {[v for v, ok in same.items() if not ok]}"), flush=True)
     lib.lmx_dbg_set_gemm2_variant(0)
     del a, w, o, r
