@@ -41,7 +41,8 @@ for v in sys.argv[1].split(","):
     cu = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
     st, me, en = [(tl[:, i].astype(np.int64) - int(t0)) / 100.0 for i in (2, 3, 4)]  # us
     si, dr = [(tl[:, i].astype(np.int64) - int(t0)) / 100.0 for i in (6, 7)]
-    print(f"  wave 0: epilogue until its stores are issued {np.mean(si - me):.2f} us, final barrier +{np.mean(en - si):.2f} us, store drain +{np.mean(dr - en):.2f} us")
+    print(f"  tile start -> first k-tile landed and all waves there {np.mean(si - st):.2f} us, -> second k-tile {np.mean(dr - si):.2f} us "
+          f"(k-loop {np.mean(me - st):.2f} us)")
     print(f"variant {v}: {len(tl)} tiles on {len(np.unique(cu))} CUs, span {en.max():.1f} us; main loop {np.mean(me - st):.2f} us, "
           f"epilogue {np.mean(en - me):.2f} us per tile")
     # co-residency: at each tile's epilogue midpoint, is another tile of the same CU in its main loop / epilogue?

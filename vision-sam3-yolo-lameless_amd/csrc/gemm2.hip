@@ -186,6 +186,10 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
     const int left = nk - 1 - kt;
     wait_tiles<PT>(left < LA - 1 ? left : LA - 1);
     __builtin_amdgcn_s_barrier();
+#ifdef LMX_DBG_TIMELINE
+    if (kt == 0) { TL(6, wall_clock64()); }
+    if (kt == 1) { TL(7, wall_clock64()); }
+#endif
     if (kt + LA < nk) issue(kt + LA, (kt + LA) % NSTAGE);
     const char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
     const half_t* as = reinterpret_cast<const half_t*>(st) + (wm * 64 + frow) * BK;
@@ -391,13 +395,8 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
       else epilogue(std::integral_constant<int, LMX_ACT_RELU>{}, F{});
     }
   }
-  TL(6, wall_clock64());
   __builtin_amdgcn_s_barrier();  // the staging slices are ring memory: nobody restages it before every wave has read its slice
   TL(4, wall_clock64());
-#ifdef LMX_DBG_TIMELINE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  TL(7, wall_clock64());
-#endif
   }  // tile loop
 }
 
