@@ -1,8 +1,7 @@
 // NOT BUILT (kept for the record; csrc/Makefile does not list it).  Round-2 experiment: measured 0-4 % ahead of the
 // one-tile-per-workgroup kernel in isolation and 0.5-1 % BEHIND it in the seven-stream bench (profiles/r02_gemm_epilogue.txt):
-// the k-loop of a 256 x 256 tile runs at the chip's aggregate L2 -> LDS rate (64 KB per CU and k-tile x 256 CUs every
-// 1.45 us = 11.5 TB/s), so the next tile's first k-tile, issued under the epilogue, only moves its cost into the epilogue
-// (3.1 -> 4.8 us per tile), whose stores share the same path.
+// the next tile's first k-tile, issued under the epilogue, only moves its cost into the epilogue (3.1 -> 4.8 us per tile),
+// whose stores share the memory path.
 // gemm2p.hip — the PERSISTENT form of gemm2.hip's 256 x 256 x 64 tiling (two 64 KB ring slots, sixteen waves of 64 x 64).
 //
 // Why: the per-tile time line of that tiling (tools/gemm_timeline_probe.py, profiles/r02_gemm_epilogue.txt) shows, per tile of
