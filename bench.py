@@ -94,7 +94,7 @@ def pmc_traffic_by_class():
             cls = "attention/mfma-bound"  # the LDS-DMA instantiations: long flat sequences (Hiera's global blocks)
         elif "attn" in name:
             cls = "attention/hbm-bound"
-        elif "ln_mlp" in name:
+        elif "mlp_kernel" in name:  # (the summary truncates long mangled names from the left)
             cls = "fused ln+mlp"
         elif "layernorm" in name:
             cls = "layernorm"
