@@ -478,7 +478,12 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
       const int64_t nt256 = (d.N + 255) / 256, tiles256 = (int64_t)((d.M + 255) / 256) * nt256;
       const double nfrac = (double)d.N / (double)(nt256 * 256);
       const double q256 = (double)tiles256 / (double)(((tiles256 + 255) / 256) * 256);
-      if (d.K >= 448 && tiles256 >= 230 && q256 >= 0.75 && (d.K < 896 ? d.N % 256 == 0 : nfrac >= 0.85)) {
+      // The rules below were re-derived with COLD A operands (tools/gemm_sweep.py LMX_SWEEP_COLD=1: buffer sets rotated so that
+      // the A operands alone exceed the 256 MB Infinity Cache).  A loop over one buffer set keeps A cache-resident and
+      // flatters the 256 x 128 tiling, which re-reads A twice as often: the qkv GEMM of Hiera stage 3 (N = 1344) measures 176 us
+      // that way with 256 x 128 and 181 with 256 x 256, but 235 vs 199 us behind the LayerNorm that produces its input, as in
+      // the model (tools/gemm_context_probe.py, profiles/r02_gemm_cold_sweep.txt).
+      if (d.K >= 448 && tiles256 >= 200 && q256 >= 0.75 && nfrac >= 0.85) {
         // 64-deep k-tiles on a 2 x 64 KB ring (half the barriers, 128-byte DMA row pieces): 4-5 % ahead of the staggered
         // 32-deep schedule at K >= 1792 (profiles/r02_gemm_sweep_interleaved.txt, variant Z) and, since the epilogue resolves
         // the activation per tile, 2-5 % ahead at K = 448 .. 1024 too (fc1 of Hiera stage 3 274 vs 289 us, DINO fc1 260 vs 265;
@@ -486,11 +491,11 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
         // 4-7 % BEHIND sixteen of 64 x 64 on every model shape: the k-loop is not bound by LDS read volume.
         return launch2<256, 256, 64, 2, 0>(d, st);
       }
-      // short K, N = 224 .. 1024 filling >= 85 % of its 256-wide tiles (Hiera's 224 / 448 / 672 / 896 with K = 112 .. 448):
-      // the plain 256 x 256 tiling wins 5-15 % over 256 x 128 (a third fewer L2->LDS bytes per flop; interleaved A/B in one
-      // process, profiles/r02_gemm_sweep_interleaved.txt); wider N (1344, 2688) loses with it
-      if (d.K <= 448 && d.N >= 224 && d.N <= 1024 && d.N % 256 != 0 && nfrac >= 0.85 && tiles256 >= 230 && q256 >= 0.75)
-        return d.K >= 448 ? launch2<256, 256, 64, 2, 0>(d, st) : launch2<256, 256, 32, 3, 0>(d, st);  // (proj of stage 3: 131 vs 135 us)
+      // short K, N = 224 .. 1536 filling >= 85 % of its 256-wide tiles (Hiera's 224 / 448 / 672 / 896 / 1344 with K = 112, 224):
+      // 256 x 256 tiles move a third fewer L2->LDS bytes per flop than 256 x 128 and win 5-15 % cold; K = 224 prefers the
+      // 32-deep 3-slot ring (N = 1344: 502 vs 518 us), K = 112 the 64-deep one (N = 672: 809 vs 841 us)
+      if (d.K < 448 && d.N >= 224 && d.N <= 1536 && d.N % 256 != 0 && nfrac >= 0.85 && tiles256 >= 200 && q256 >= 0.75)
+        return d.K > 128 ? launch2<256, 256, 32, 3, 0>(d, st) : launch2<256, 256, 64, 2, 0>(d, st);
       const int64_t tiles = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128);
       return (d.K >= 1792 || tiles <= 256) ? launch2<256, 128, 64, 3, 0, 1>(d, st) : launch2<256, 128, 32, 3, 0>(d, st);
     }
