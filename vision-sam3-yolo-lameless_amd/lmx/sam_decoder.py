@@ -190,18 +190,19 @@ class MaskDecoder:
             queries = K.gemm(h, *L["w2"], res=queries, out_dtype=torch.float32)
             queries = K.layernorm(queries, *L["ln3"], eps, out_dtype=torch.float32)
             q16 = K.add_bcast(queries, qpe, out_dtype=torch.float16)
-            k16 = K.add_bcast(keys, self.key_pe, out_dtype=torch.float16)
+            # (keys have not changed since the token-to-image attention above: k16 is still keys + key_pe)
             keys = self._attn(L["i2t"], k16, q16, K.cast_f16(queries), n, P, T, keys)
             keys = K.layernorm(keys, *L["ln4"], eps, out_dtype=torch.float32)
         q16 = K.add_bcast(queries, qpe, out_dtype=torch.float16)
         k16 = K.add_bcast(keys, self.key_pe, out_dtype=torch.float16)
-        queries = self._attn(self.final, q16, k16, K.cast_f16(keys), n, T, P, queries)
+        keys16 = K.cast_f16(keys)  # the final attention's values and the upscaler's input
+        queries = self._attn(self.final, q16, k16, keys16, n, T, P, queries)
         queries = K.layernorm(queries, *self.ln_final, 1e-5, out_dtype=torch.float32)
         q3 = queries.view(n, T, D)
         iou_tok = K.cast_f16(q3[:, 0].contiguous())
         mask_tok = K.cast_f16(q3[:, 1].contiguous())
         # upscaler: per-pixel GEMMs, LayerNorm2d+GELU row-wise on the [.., quadrant, 64] view, pixel shuffle deferred
-        u = K.gemm(K.cast_f16(keys), *self.up1, out_dtype=torch.float32)            # [n*P, 4*64]
+        u = K.gemm(keys16, *self.up1, out_dtype=torch.float32)                       # [n*P, 4*64]
         u = K.layernorm(u.view(n * P * 4, 64), *self.up_ln, eps, act=K.ACT_GELU)      # f16 [n*P*4, 64]
         u = K.gemm(u, *self.up2, act=K.ACT_GELU)                                     # f16 [n*P*4, 4*32]
         hyper = self._ffn(self.hyper0, mask_tok)                                     # f32 [n,32]
