@@ -65,6 +65,29 @@ def test_gemm_epilogues(cuda, act, M):
     _close(got, ref16, 4e-3, 2e-3, f"gemm f16 epilogue act={act}")
 
 
+@pytest.mark.parametrize("n,H,W,K,N", [(3, 20, 20, 112, 224), (2, 64, 64, 224, 448), (5, 16, 16, 448, 896), (1, 30, 26, 72, 104)])
+def test_gemm_pooled_rows_equal_gemm_then_maxpool(cuda, n, H, W, K, N):
+    """a_mode 2 (Hiera's do_pool(proj(x)) in one launch): bit for bit the f32 GEMM followed by maxpool2, ragged last tile,
+    several images, N not a multiple of the tile width."""
+    from lmx import kernels as Kk
+
+    M = n * H * W
+    a = _rand((M, K), 21).half().to(cuda)
+    w = _rand((N, K), 22, K ** -0.5).half().to(cuda)
+    b = _rand((N,), 23).to(cuda)
+    full = Kk.gemm(a, w, bias=b, out_dtype=torch.float32)
+    ref = torch.empty((n, H // 2, W // 2, N), dtype=torch.float32, device=cuda)
+    Kk.maxpool2(full.view(n, H, W, N), ref)
+    got = Kk.gemm(a, w, bias=b, out_dtype=torch.float32, pool_hw=(H, W))
+    assert got.shape == (M // 4, N)
+    assert torch.equal(got, ref.view(-1, N))
+    # and against plain fp32 arithmetic
+    want = F.max_pool2d((a.float() @ w.float().t() + b).view(n, H, W, N).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).reshape(-1, N)
+    _close(got, want, 2e-4, 1e-4, "pooled gemm")
+    with pytest.raises(Exception):
+        Kk.gemm(a[:64], w, bias=b, out_dtype=torch.float32, pool_hw=(8, 8))  # below the LDS-DMA kernel's sizes: refused loudly
+
+
 @pytest.mark.parametrize("n,H,W,Cin,Cout,stride", [(2, 20, 20, 64, 128, 1), (1, 33, 47, 16, 24, 2), (2, 40, 24, 128, 64, 2),
                                                     (1, 80, 80, 256, 256, 1)])
 def test_conv3x3(cuda, n, H, W, Cin, Cout, stride):

@@ -36,6 +36,12 @@ __device__ __forceinline__ float act_apply(float v, int act) { return lmx_act(v,
 // AMODE 1: A is generated from an NHWC image batch (3x3, pad 1, stride 1|2; gemm.hip's a_mode 1) — requires Cin % BK == 0
 // so that a k-tile lies inside one filter tap: the tap (ky,kx) is then wave-uniform per k-tile and a lane only adds a
 // constant to its pixel offset; out-of-image taps take the out-of-range offset and the descriptor returns zeros.
+// AMODE 2: "pooled rows" — the A rows are a [n][H][W] token grid and the OUTPUT is its 2 x 2 max-pool: GEMM row m reads token
+// (image, 2*gy + (m&3)/2, 2*gx + (m&3)%2) of pool group m/4 = (image, gy, gx), so the four tokens of a group are four
+// consecutive accumulator rows of one wave; the epilogue takes their maximum (two lane shuffles) and writes ONE row, M/4 in
+// all.  Replaces GEMM (f32, 4 B per element written) + maxpool2 (read back, written again) at Hiera's stage transitions
+// (TF sam2 Sam2MultiScaleBlock: `do_pool(self.proj(hidden_states))`); max commutes with nothing that is done before it
+// here (bias is added first, as the unfused kernels do), so the bits are those of the two-kernel form.
 // STAG 1: the two halves of the waves (w and w + NWAVE/2 share a SIMD) run ONE barrier interval apart, and a k-tile is
 // two intervals: X = fragment reads + counted vmcnt + next LDS-DMA, Y = the MFMAs.  While one wave of a SIMD is in Y the
 // other is in X: the matrix pipe sees MFMAs in every interval instead of every second one (guide: 8-phase template).
@@ -86,10 +92,10 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   const int hw_out = (AMODE == 1) ? p.Ho * p.Wo : 1;
   const int img0 = (AMODE == 1) ? m0 / hw_out : 0;  // first image touched by this tile
   const char* Ab = reinterpret_cast<const char*>(p.A) +
-                   ((AMODE == 1) ? (int64_t)img0 * p.H * p.W_ * p.lda * 2 : (int64_t)m0 * p.lda * 2);
+                   ((AMODE == 1) ? (int64_t)img0 * p.H * p.W_ * p.lda * 2 : (AMODE == 2 ? (int64_t)0 : (int64_t)m0 * p.lda * 2));
   const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.K * 2;
   int64_t a_bytes = (AMODE == 1) ? ((int64_t)(p.M / hw_out - img0) * p.H * p.W_ - 1) * p.lda * 2 + (int64_t)p.Cin * 2
-                                 : ((int64_t)(p.M - m0 - 1) * p.lda + p.K) * 2;
+                                 : ((int64_t)(p.M - (AMODE == 2 ? 0 : m0) - 1) * p.lda + p.K) * 2;
   int64_t w_bytes = (int64_t)(p.N - n0) * p.K * 2;
   if (a_bytes > 0x7FFFFFF0ll) a_bytes = 0x7FFFFFF0ll;
   if (w_bytes > 0x7FFFFFF0ll) w_bytes = 0x7FFFFFF0ll;
@@ -109,6 +115,14 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
     const int row = (wave * A_INSTR + j) * ROWS_PER_INSTR + lrow;
     if (AMODE == 0) {
       a_off[j] = (unsigned)(row * (int)p.lda * 2 + lchunk * 16);
+      a_yx[j] = 0;
+    } else if (AMODE == 2) {
+      const int m = m0 + row, g = m >> 2, sub = m & 3;
+      const int Wq = p.W_ >> 1, gpi = (p.H >> 1) * Wq;  // pool groups per image row / per image
+      const int img = g / gpi, rem = g - img * gpi;
+      const int gy = rem / Wq, gx = rem - gy * Wq;
+      const int tok = (img * p.H + 2 * gy + (sub >> 1)) * p.W_ + 2 * gx + (sub & 1);
+      a_off[j] = m < p.M ? (unsigned)(tok * (int)p.lda * 2 + lchunk * 16) : 0x80000000u;  // (the whole A is < 2 GB: checked by the caller)
       a_yx[j] = 0;
     } else {
       const int m = m0 + row;
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
     char* st = smem + slot * STAGE_BYTES;
     const bool kill = (kt == nk - 1) && k_tail_lane;
     const int soff = kt * (BK * 2);
-    if (AMODE == 0) {
+    if (AMODE != 1) {
 #pragma unroll
       for (int j = 0; j < A_INSTR; ++j) {
         char* dst = st + (wave * A_INSTR + j) * 1024;
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   float* bl = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);  // [2][BN]
   // (the convolution variant has no registers to spare across its k-loop and asks after it)
   float bias_v = 0.f, scale_v = 1.f;
-  if (AMODE == 0 && tid < BN && n0 + tid < p.N) {
+  if (AMODE != 1 && tid < BN && n0 + tid < p.N) {
     if (p.bias) bias_v = p.bias[n0 + tid];
     if (p.scale) scale_v = p.scale[n0 + tid];
   }
@@ -338,6 +352,25 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
           }
         }
       }
+    } else if constexpr (AMODE == 2) {
+      // pooled rows: the four tokens of a pool group are accumulator rows 4q .. 4q+3 of a 16-row block = lanes that differ in
+      // bits 0-1 of the row index; their maximum goes out as one row, straight from the accumulator layout (16 bytes per lane,
+      // 64 contiguous bytes per output row and instruction: a quarter of the rows, so the transposer is not worth its trip)
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v = finish(acc[pass][j], j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = fmaxf(v[e], __shfl_xor(v[e], 1, 64));
+            v[e] = fmaxf(v[e], __shfl_xor(v[e], 2, 64));
+          }
+          const int m = m0 + wm * 64 + pass * 16 + frow;
+          const int n = n0 + wn * 64 + j * 16 + fq * 4;
+          if ((frow & 3) == 0 && m < p.M && n < p.N) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)(m >> 2) * p.ldc + n) = v;
+          __builtin_amdgcn_sched_barrier(0);  // one fragment at a time: interleaved, the sixteen of them spill
+        }
     } else {
       float* t32 = reinterpret_cast<float*>(my);
       constexpr int RS = 68;  // floats per LDS row: 64 + 4
@@ -443,6 +476,7 @@ int lmx_gemm2_launch(const lmx_gemm_desc& d, hipStream_t st) {
     g_variant = e ? e[0] : 0;
   }
   const int variant = g_variant;
+  if (d.a_mode == 2) return launch2<256, 256, 64, 2, 2>(d, st);  // pooled rows (f32 out): one tiling
   if (d.a_mode == 1) {  // 3x3 convolution, Cin % 32 == 0 (checked by the caller)
     static int conv_small = -1;
     if (conv_small < 0) conv_small = getenv("LMX_GEMM2_CONV_SMALL") ? 1 : 0;

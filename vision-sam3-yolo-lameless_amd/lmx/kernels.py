@@ -50,9 +50,17 @@ def _rows(t, what):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
-def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtype=torch.float16, res_rows=0):
+def pooled_gemm_ok(M, N):
+    """Shapes lmx_k_gemm's pooled-row mode (a_mode 2) is built for (the LDS-DMA kernel); smaller ones take GEMM + maxpool2."""
+    return M >= 512 and N >= 96 and N % 8 == 0
+
+
+def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtype=torch.float16, res_rows=0, pool_hw=None):
     """out[M,N] = res + scale * act(a[M,K] @ w[N,K]^T + bias)   (lmx_k_gemm, a_mode 0).
-    res_rows > 0: res is a [res_rows, N] table broadcast over the batch (row m uses res[m % res_rows])."""
+    res_rows > 0: res is a [res_rows, N] table broadcast over the batch (row m uses res[m % res_rows]).
+    pool_hw=(H, W): the rows of `a` are an [n, H, W] token grid and the result is the 2 x 2 max-pool of the product over that
+    grid, f32 [M/4, N] in [n, H/2, W/2] order (a_mode 2: the bits of gemm(...) followed by maxpool2, without the full-size
+    intermediate)."""
     _dev(a, w, bias, scale, res, out)
     M, K, lda = _rows(a, "gemm A")
     N, K2, ldw = _rows(w, "gemm W")
@@ -60,11 +68,14 @@ def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtyp
         raise LmxError(f"gemm: W must be contiguous [N,K]; A K={K}, W shape {tuple(w.shape)}")
     if a.dtype != torch.float16 or w.dtype != torch.float16:
         raise LmxError("gemm: A and W must be float16")
+    Mout = M // 4 if pool_hw else M
+    if pool_hw and (out_dtype != torch.float32 and out is None):
+        raise LmxError("gemm: pooled rows give float32")
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+        out = torch.empty((Mout, N), dtype=out_dtype, device=a.device)
     Mo, No, ldc = _rows(out, "gemm C")
-    if (Mo, No) != (M, N):
-        raise LmxError(f"gemm: out shape {tuple(out.shape)} != ({M},{N})")
+    if (Mo, No) != (Mout, N):
+        raise LmxError(f"gemm: out shape {tuple(out.shape)} != ({Mout},{N})")
     d = GemmDesc()
     d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -82,6 +93,8 @@ def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtyp
     d.res_rows = res_rows
     d.M, d.N, d.K = M, N, K
     d.act, d.out_dtype, d.a_mode = act, _DT[out.dtype], 0
+    if pool_hw:
+        d.a_mode, d.H, d.W_ = 2, int(pool_hw[0]), int(pool_hw[1])
     check(_lib.load().lmx_k_gemm(C.byref(d), _stream()), "lmx_k_gemm")
     return out
 
@@ -506,7 +519,7 @@ def _work(name, args):
         a_bytes = 2 * M * Kd
         if d.a_mode == 1:  # 3x3 implicit GEMM: the input image is read once, not 9 times
             a_bytes = 2 * (M // max(d.Ho * d.Wo, 1)) * d.H * d.W_ * d.Cin
-        by = a_bytes + 2 * N * Kd + osz * M * N + (osz * (d.res_rows or M) * N if d.res else 0)
+        by = a_bytes + 2 * N * Kd + osz * (M // 4 if d.a_mode == 2 else M) * N + (osz * (d.res_rows or M) * N if d.res else 0)
         fl = 2.0 * M * N * Kd
         key = f"gemm M={M} N={N} K={Kd} out={'f32' if osz == 4 else 'f16'} conv3x3={d.a_mode} act={d.act} res={int(bool(d.res))}"
         return ("gemm/mfma-bound" if fl / by >= RIDGE_FLOP_PER_BYTE else "gemm/hbm-bound"), fl, by, key

@@ -194,11 +194,14 @@ class HieraEncoder:
             rows = n * H * W
             h = K.layernorm(x, B["g1"], B["b1"], cfg.eps)
             if dim != D:
-                sc = K.gemm(h, B["wp"], bias=B["bp"], out_dtype=torch.float32)
-                if qs:
-                    pooled = torch.empty((n, H // 2, W // 2, D), dtype=torch.float32, device=dev)
-                    K.maxpool2(sc.view(n, H, W, D), pooled)
-                    sc = pooled.view(-1, D)
+                if qs and K.pooled_gemm_ok(rows, D):  # the shortcut's projection and its 2 x 2 max-pool in one launch
+                    sc = K.gemm(h, B["wp"], bias=B["bp"], out_dtype=torch.float32, pool_hw=(H, W))
+                else:
+                    sc = K.gemm(h, B["wp"], bias=B["bp"], out_dtype=torch.float32)
+                    if qs:
+                        pooled = torch.empty((n, H // 2, W // 2, D), dtype=torch.float32, device=dev)
+                        K.maxpool2(sc.view(n, H, W, D), pooled)
+                        sc = pooled.view(-1, D)
                 res = sc
             else:
                 res = x
