@@ -186,6 +186,10 @@ def test_ln_mlp_fused(cuda, rows, D):
     u = Kk.gemm(h, dev[2], bias=dev[3], act=Kk.ACT_GELU)
     Kk.gemm(u, dev[4], bias=dev[5], res=xu, out=xu)
     _close(got, xu, 2e-3, 1e-3, "fused ln_mlp vs unfused launches")
+    # the optional f16 copy of the result is what a cast of the f32 result gives, and asking for it changes nothing else
+    x16 = torch.full((rows, D), 7.0, dtype=torch.float16, device=cuda)
+    got2 = Kk.ln_mlp(x.clone().to(cuda), *dev, 1e-6, x16=x16)
+    assert torch.equal(got2, got) and torch.equal(x16, Kk.cast_f16(got))
 
 
 def test_ln_mlp_rejects_other_widths(cuda):

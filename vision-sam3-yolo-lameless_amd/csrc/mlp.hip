@@ -37,7 +37,8 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
                                                                           const half_t* __restrict__ w1,
                                                                           const float* __restrict__ b1,
                                                                           const half_t* __restrict__ w2,
-                                                                          const float* __restrict__ b2, int64_t rows) {
+                                                                          const float* __restrict__ b2, int64_t rows,
+                                                                          half_t* __restrict__ x16) {
   constexpr int KS = (D + 31) / 32;           // k-steps of the first GEMM
   constexpr int DP = D <= 128 ? 128 : 256;    // halfs per LDS row of a W1 chunk (power of two: XOR swizzle stays in the row)
   constexpr int DB = D / 16;                  // 16-wide output blocks
@@ -253,13 +254,21 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
       float* xr = x + t * ldx;
 #pragma unroll
       for (int db = 0; db < DB; ++db) *reinterpret_cast<f32x4*>(xr + db * 16 + fg * 4) = oacc[qb][db];
+      if (x16) {  // the stage's last block also leaves an f16 copy for the FPN's lateral convolution (what lmx_k_cast_f32_f16 made)
+        half_t* hr = x16 + t * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const f32x4 v = oacc[qb][db];
+          *reinterpret_cast<half4_t*>(hr + db * 16 + fg * 4) = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+      }
     }
   }
 }
 
 template <int D, int QB, int NW, int NST, int OCC, bool INLN>
 int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const float* bet, float eps, const half_t* w1, const float* b1,
-           const half_t* w2, const float* b2, int64_t rows, hipStream_t st) {
+           const half_t* w2, const float* b2, int64_t rows, half_t* x16, hipStream_t st) {
   constexpr int DP = D <= 128 ? 128 : 256;
   const size_t smem = (size_t)NST * (HC * DP * 2 + DP * 64) + 4 * D * sizeof(float);
   static bool attr_set = false;
@@ -272,7 +281,7 @@ int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const floa
   const int64_t nb = (rows + per - 1) / per;
   LMX_REQUIRE(nb < 0x7fffffffll, "lmx_k_ln_mlp: too many rows");
   hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC, INLN>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, hn, gam, bet, eps, w1, b1, w2,
-                     b2, rows);
+                     b2, rows, x16);
   return lmx_launch_check("ln_mlp_kernel");
 }
 
@@ -280,7 +289,8 @@ int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const floa
 using namespace lmx_mlp;
 
 extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const float* beta, const void* w1, const float* b1,
-                            const void* w2, const float* b2, int64_t rows, int D, float eps, void* workspace, lmx_stream_t stream) {
+                            const void* w2, const float* b2, int64_t rows, int D, float eps, void* workspace, void* x16,
+                            lmx_stream_t stream) {
   LMX_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && workspace, "lmx_k_ln_mlp: null pointer");
   LMX_REQUIRE(D == 112 || D == 224, "lmx_k_ln_mlp: D=%d (built for the Hiera stage widths 112 and 224)", D);
   LMX_REQUIRE(rows > 0 && rows < 0x7fffffffll && ldx >= D && ldx % 4 == 0, "lmx_k_ln_mlp: rows=%lld ldx=%lld", (long long)rows,
@@ -291,6 +301,8 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const half_t* W1 = reinterpret_cast<const half_t*>(w1);
   const half_t* W2 = reinterpret_cast<const half_t*>(w2);
+  half_t* X16 = reinterpret_cast<half_t*>(x16);
+  LMX_REQUIRE(!x16 || ((((uintptr_t)x16) & 7) == 0), "lmx_k_ln_mlp: x16 must be 8-byte aligned");
   static int one_per_cu = -1, split_ln = 0;  // LMX_MLP_ONE_PER_CU=1: the 8-wave, one-workgroup-per-CU configuration of the narrow width too
   if (one_per_cu < 0) {
     one_per_cu = getenv("LMX_MLP_ONE_PER_CU") ? 1 : 0;
@@ -298,15 +310,15 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
   }
   // D = 112: 4 waves x 32 tokens, 48 KB ring, three workgroups per CU.  D = 224: 8 waves x 32 tokens, 128 KB ring, one per CU.
   if (!split_ln) {
-    if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, st);
-    if (D == 112) return launch<112, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, st);
-    return launch<224, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, st);
+    if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
+    if (D == 112) return launch<112, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
+    return launch<224, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
   }
   // 1. LayerNorm (norm.hip; f32 stream -> f16 [rows, D] in the workspace), 2. the fused MLP + residual on it
   const int rc = lmx_k_layernorm(x, LMX_F32, ldx, gamma, beta, workspace, LMX_F16, D, (int)rows, D, eps, LMX_ACT_NONE, stream);
   if (rc) return rc;
   const half_t* hn = reinterpret_cast<const half_t*>(workspace);
-  if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, st);
-  if (D == 112) return launch<112, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, st);
-  return launch<224, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, st);
+  if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
+  if (D == 112) return launch<112, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
+  return launch<224, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
 }

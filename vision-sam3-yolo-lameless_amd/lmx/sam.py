@@ -186,7 +186,7 @@ class HieraEncoder:
         x = K.gemm(patches, self.pe_w, bias=self.pe_b, res=self.pos, res_rows=g * g, out_dtype=torch.float32)
         H = W = g
         stage_ends = set(int(v) for v in np.cumsum(cfg.blocks) - 1)
-        stages = []
+        stages, stages16 = [], []
         dev = x.device
         for i, B in enumerate(self.blocks):
             dim, D, heads, win, qs = B["dim"], B["dim_out"], B["heads"], B["win"], B["qs"]
@@ -226,26 +226,30 @@ class HieraEncoder:
             xo = torch.empty((n * H * W, D), dtype=torch.float32, device=dev) if res is not x else x
             K.gemm(a, B["wo"], bias=B["bo"], res=res, out=xo)
             x = xo
+            x16 = None
             if D in K.FUSED_MLP_WIDTHS and self.fused_mlp:
-                K.ln_mlp(x, B["g2"], B["b2"], B["w1"], B["bb1"], B["w2"], B["bb2"], cfg.eps)  # one pass over x (csrc/mlp.hip)
+                if i in stage_ends:  # the FPN's lateral convolution reads this stage output as f16: written here, not cast later
+                    x16 = torch.empty((n * H * W, D), dtype=torch.float16, device=dev)
+                K.ln_mlp(x, B["g2"], B["b2"], B["w1"], B["bb1"], B["w2"], B["bb2"], cfg.eps, x16=x16)  # one pass over x (csrc/mlp.hip)
             else:
                 h2 = K.layernorm(x, B["g2"], B["b2"], cfg.eps)
                 u = K.gemm(h2, B["w1"], bias=B["bb1"], act=K.ACT_GELU)
                 K.gemm(u, B["w2"], bias=B["bb2"], res=x, out=x)
             if i in stage_ends:
                 stages.append(x.view(n, H, W, D))
+                stages16.append(x16)
                 if i != len(self.blocks) - 1 and self.blocks[i + 1]["dim"] == self.blocks[i + 1]["dim_out"]:
                     x = x.clone()  # the stage output is kept; a same-width next block would update it in place
-        return stages
+        return stages, stages16  # stages16: f16 copies of the stage outputs where the stage's last kernel wrote one (else None)
 
-    def fpn(self, stages):
+    def fpn(self, stages, stages16=None):
         cfg = self.cfg
         nlev = len(stages) - 1
         feats, prev = [], None
         for i in range(nlev, -1, -1):
             s = stages[i]
             n, H, W, C = s.shape
-            a = K.cast_f16(s.view(-1, C))
+            a = stages16[i] if stages16 and stages16[i] is not None else K.cast_f16(s.view(-1, C))
             w, b = self.neck[i]
             out = torch.empty((n, H, W, cfg.fpn_dim), dtype=torch.float16, device=s.device)
             if i not in cfg.fpn_top_down or i == nlev:
@@ -259,8 +263,8 @@ class HieraEncoder:
         return feats[-3:][::-1]
 
     def encode_patches(self, patches, n):
-        stages = self.trunk(patches, n)
-        return dict(fpn=self.fpn(stages), stages=stages)
+        stages, stages16 = self.trunk(patches, n)
+        return dict(fpn=self.fpn(stages, stages16), stages=stages)
 
     def encode(self, frames):
         img, patches = self.preprocess(frames)
