@@ -100,9 +100,13 @@ int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const float* gamma
  * Rounding points match the unfused kernels: LN output and GELU output are rounded to f16, accumulation is f32.
  */
 int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const float* beta, const void* w1, const float* b1,
-                 const void* w2, const float* b2, int64_t rows, int D, float eps, void* workspace, void* x16, lmx_stream_t stream);
+                 const void* w2, const float* b2, int64_t rows, int D, float eps, void* workspace, void* x16,
+                 const float* gamma_next, const float* beta_next, void* h_next, lmx_stream_t stream);
 /* x16: NULL, or f16 [rows, D] (contiguous) that receives a copy of the updated x — the input of the FPN's lateral 1x1
- * convolution after a stage's last block, which otherwise costs a cast pass over the f32 stream */
+ * convolution after a stage's last block, which otherwise costs a cast pass over the f32 stream.
+ * h_next: NULL, or f16 [rows, D] that receives LayerNorm(updated x; gamma_next, beta_next, eps) — the NEXT block's
+ * `layer_norm1(hidden_states)`, computed on the rows while they are still in registers instead of by a LayerNorm launch
+ * that reads the f32 stream again */
 
 /* ---- K13/K14: attention (flash-style, online softmax in f32, S and PV on MFMA) ----------------------
  * O[b,t,h,:] = softmax_j( scale * Q[b,t,h,:] . K[b,j,h,:] ) V[b,j,h,:]

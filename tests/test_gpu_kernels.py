@@ -190,6 +190,14 @@ def test_ln_mlp_fused(cuda, rows, D):
     x16 = torch.full((rows, D), 7.0, dtype=torch.float16, device=cuda)
     got2 = Kk.ln_mlp(x.clone().to(cuda), *dev, 1e-6, x16=x16)
     assert torch.equal(got2, got) and torch.equal(x16, Kk.cast_f16(got))
+    # the next block's LayerNorm from the same launch: the rows' statistics are reduced in another order than the LayerNorm
+    # kernel's, so equality is to f16 rounding, not to the bit
+    gn, bn = (_rand((D,), 77) * 0.1 + 1).to(cuda), (_rand((D,), 78) * 0.1).to(cuda)
+    hn = torch.full((rows, D), 7.0, dtype=torch.float16, device=cuda)
+    got3 = Kk.ln_mlp(x.clone().to(cuda), *dev, 1e-6, next_ln=(gn, bn, hn))
+    assert torch.equal(got3, got)
+    _close(hn, Kk.layernorm(got, gn, bn, 1e-6), 2e-3, 2e-3, "next-block LayerNorm from the fused MLP")
+    _close(hn, F.layer_norm(got.float().cpu(), (D,), gn.cpu(), bn.cpu(), 1e-6), 2e-3, 2e-3, "next-block LayerNorm vs torch")
 
 
 def test_ln_mlp_rejects_other_widths(cuda):

@@ -38,7 +38,10 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
                                                                           const float* __restrict__ b1,
                                                                           const half_t* __restrict__ w2,
                                                                           const float* __restrict__ b2, int64_t rows,
-                                                                          half_t* __restrict__ x16) {
+                                                                          half_t* __restrict__ x16,
+                                                                          const float* __restrict__ gam_n,
+                                                                          const float* __restrict__ bet_n,
+                                                                          half_t* __restrict__ h_n) {
   constexpr int KS = (D + 31) / 32;           // k-steps of the first GEMM
   constexpr int DP = D <= 128 ? 128 : 256;    // halfs per LDS row of a W1 chunk (power of two: XOR swizzle stays in the row)
   constexpr int DB = D / 16;                  // 16-wide output blocks
@@ -263,12 +266,48 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
         }
       }
     }
+    // the NEXT block's LayerNorm on the rows this wave just finished (they are all in registers: a token's D features sit in
+    // its four lanes): h_n = LayerNorm(x; gam_n, bet_n) in f16, the input of that block's qkv projection — the standalone
+    // LayerNorm launch it replaces reads the f32 stream again.  Same arithmetic form as the LayerNorm at the top of this kernel.
+    if (h_n) {
+      float sm = 0.f;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const f32x4 v = oacc[qb][db];
+        sm += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      const float mean = sm * (1.0f / D);
+      float sq = 0.f;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const f32x4 a = oacc[qb][db] - mean;
+        sq += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+      }
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      const float rstd = __builtin_amdgcn_rsqf(sq * (1.0f / D) + eps);
+      if (t < rows) {
+        half_t* hr = h_n + t * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const int d = db * 16 + fg * 4;
+          const f32x4 g = *reinterpret_cast<const f32x4*>(gam_n + d), c = *reinterpret_cast<const f32x4*>(bet_n + d);
+          const f32x4 v = oacc[qb][db];
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)((v[e] - mean) * rstd * g[e] + c[e]);
+          *reinterpret_cast<half4_t*>(hr + d) = o;
+        }
+      }
+    }
   }
 }
 
 template <int D, int QB, int NW, int NST, int OCC, bool INLN>
 int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const float* bet, float eps, const half_t* w1, const float* b1,
-           const half_t* w2, const float* b2, int64_t rows, half_t* x16, hipStream_t st) {
+           const half_t* w2, const float* b2, int64_t rows, half_t* x16, const float* gam_n, const float* bet_n, half_t* h_n, hipStream_t st) {
   constexpr int DP = D <= 128 ? 128 : 256;
   const size_t smem = (size_t)NST * (HC * DP * 2 + DP * 64) + 4 * D * sizeof(float);
   static bool attr_set = false;
@@ -281,7 +320,7 @@ int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const floa
   const int64_t nb = (rows + per - 1) / per;
   LMX_REQUIRE(nb < 0x7fffffffll, "lmx_k_ln_mlp: too many rows");
   hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC, INLN>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, hn, gam, bet, eps, w1, b1, w2,
-                     b2, rows, x16);
+                     b2, rows, x16, gam_n, bet_n, h_n);
   return lmx_launch_check("ln_mlp_kernel");
 }
 
@@ -290,7 +329,7 @@ using namespace lmx_mlp;
 
 extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const float* beta, const void* w1, const float* b1,
                             const void* w2, const float* b2, int64_t rows, int D, float eps, void* workspace, void* x16,
-                            lmx_stream_t stream) {
+                            const float* gamma_next, const float* beta_next, void* h_next, lmx_stream_t stream) {
   LMX_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && workspace, "lmx_k_ln_mlp: null pointer");
   LMX_REQUIRE(D == 112 || D == 224, "lmx_k_ln_mlp: D=%d (built for the Hiera stage widths 112 and 224)", D);
   LMX_REQUIRE(rows > 0 && rows < 0x7fffffffll && ldx >= D && ldx % 4 == 0, "lmx_k_ln_mlp: rows=%lld ldx=%lld", (long long)rows,
@@ -302,6 +341,9 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
   const half_t* W1 = reinterpret_cast<const half_t*>(w1);
   const half_t* W2 = reinterpret_cast<const half_t*>(w2);
   half_t* X16 = reinterpret_cast<half_t*>(x16);
+  half_t* HN = reinterpret_cast<half_t*>(h_next);
+  LMX_REQUIRE(!h_next || (gamma_next && beta_next && aligned16(gamma_next) && aligned16(beta_next) && ((((uintptr_t)h_next) & 7) == 0)),
+              "lmx_k_ln_mlp: h_next needs gamma_next / beta_next (16-byte aligned) and an 8-byte aligned output");
   LMX_REQUIRE(!x16 || ((((uintptr_t)x16) & 7) == 0), "lmx_k_ln_mlp: x16 must be 8-byte aligned");
   static int one_per_cu = -1, split_ln = 0;  // LMX_MLP_ONE_PER_CU=1: the 8-wave, one-workgroup-per-CU configuration of the narrow width too
   if (one_per_cu < 0) {
@@ -310,15 +352,15 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
   }
   // D = 112: 4 waves x 32 tokens, 48 KB ring, three workgroups per CU.  D = 224: 8 waves x 32 tokens, 128 KB ring, one per CU.
   if (!split_ln) {
-    if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
-    if (D == 112) return launch<112, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
-    return launch<224, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
+    if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+    if (D == 112) return launch<112, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+    return launch<224, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
   }
   // 1. LayerNorm (norm.hip; f32 stream -> f16 [rows, D] in the workspace), 2. the fused MLP + residual on it
   const int rc = lmx_k_layernorm(x, LMX_F32, ldx, gamma, beta, workspace, LMX_F16, D, (int)rows, D, eps, LMX_ACT_NONE, stream);
   if (rc) return rc;
   const half_t* hn = reinterpret_cast<const half_t*>(workspace);
-  if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
-  if (D == 112) return launch<112, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
-  return launch<224, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, X16, st);
+  if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  if (D == 112) return launch<112, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  return launch<224, 2, 8, 4, 1, false>(x, ldx, hn, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
 }

@@ -219,10 +219,12 @@ def pack_bits(mask):
 FUSED_MLP_WIDTHS = (112, 224)
 
 
-def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps, x16=None):
+def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps, x16=None, next_ln=None):
     """x (f32 [rows, D], updated in place) += fc2(gelu(fc1(LayerNorm(x)))) for D in FUSED_MLP_WIDTHS (csrc/mlp.hip).
-    x16: optional f16 [rows, D] that also receives the updated x (saves a cast pass where an f16 copy is needed next)."""
-    _dev(x, gamma, beta, w1, b1, w2, b2, x16)
+    x16: optional f16 [rows, D] that also receives the updated x (saves a cast pass where an f16 copy is needed next).
+    next_ln=(gamma, beta, h): h (f16 [rows, D]) receives LayerNorm(updated x; gamma, beta, eps) — the next block's first
+    LayerNorm, without its launch."""
+    _dev(x, gamma, beta, w1, b1, w2, b2, x16, *(next_ln or ()))
     rows, D, ldx = _rows(x, "ln_mlp x")
     if x.dtype != torch.float32 or w1.dtype != torch.float16 or w2.dtype != torch.float16:
         raise LmxError("ln_mlp: x must be f32 and the weights f16")
@@ -230,9 +232,12 @@ def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps, x16=None):
         raise LmxError("ln_mlp: weight shapes must be [4D, D] and [D, 4D], contiguous")
     if x16 is not None and (x16.dtype != torch.float16 or tuple(x16.shape) != (rows, D) or not x16.is_contiguous()):
         raise LmxError("ln_mlp: x16 must be contiguous float16 [rows, D]")
+    gn, bn, hn = next_ln if next_ln else (None, None, None)
+    if hn is not None and (hn.dtype != torch.float16 or tuple(hn.shape) != (rows, D) or not hn.is_contiguous() or gn.numel() != D or bn.numel() != D):
+        raise LmxError("ln_mlp: next_ln = (gamma [D], beta [D], contiguous float16 [rows, D])")
     ws = torch.empty((rows, D), dtype=torch.float16, device=x.device)  # LayerNorm output (the library's workspace)
     check(_lib.load().lmx_k_ln_mlp(_ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), rows, D,
-                                   float(eps), _ptr(ws), _ptr(x16) if x16 is not None else None, _stream()), "lmx_k_ln_mlp")
+                                   float(eps), _ptr(ws), _ptr(x16), _ptr(gn), _ptr(bn), _ptr(hn), _stream()), "lmx_k_ln_mlp")
     return x
 
 
@@ -537,7 +542,7 @@ def _work(name, args):
         return "layernorm", 0.0, rows * D * ((4 if in_dt == F32 else 2) + (4 if out_dt == F32 else 2)), f"layernorm rows={rows} D={D} in={in_dt} out={out_dt}"
     if name == "lmx_k_ln_mlp":
         rows, D = args[8], args[9]
-        return "fused ln+mlp", 16.0 * D * D * rows, (18 if args[12] else 16) * D * rows, f"ln_mlp rows={rows} D={D}"
+        return "fused ln+mlp", 16.0 * D * D * rows, (16 + (2 if args[12] else 0) + (2 if args[15] else 0)) * D * rows, f"ln_mlp rows={rows} D={D}"
     return "pre/post-processing and glue", 0.0, None, name
 
 

@@ -188,11 +188,14 @@ class HieraEncoder:
         stage_ends = set(int(v) for v in np.cumsum(cfg.blocks) - 1)
         stages, stages16 = [], []
         dev = x.device
+        h_next = None
         for i, B in enumerate(self.blocks):
             dim, D, heads, win, qs = B["dim"], B["dim_out"], B["heads"], B["win"], B["qs"]
             hd = D // heads
             rows = n * H * W
-            h = K.layernorm(x, B["g1"], B["b1"], cfg.eps)
+            # (a block whose predecessor ran the fused MLP gets its LayerNorm from that kernel: h_next)
+            h = h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps)
+            h_next = None
             if dim != D:
                 if qs and K.pooled_gemm_ok(rows, D):  # the shortcut's projection and its 2 x 2 max-pool in one launch
                     sc = K.gemm(h, B["wp"], bias=B["bp"], out_dtype=torch.float32, pool_hw=(H, W))
@@ -230,7 +233,11 @@ class HieraEncoder:
             if D in K.FUSED_MLP_WIDTHS and self.fused_mlp:
                 if i in stage_ends:  # the FPN's lateral convolution reads this stage output as f16: written here, not cast later
                     x16 = torch.empty((n * H * W, D), dtype=torch.float16, device=dev)
-                K.ln_mlp(x, B["g2"], B["b2"], B["w1"], B["bb1"], B["w2"], B["bb2"], cfg.eps, x16=x16)  # one pass over x (csrc/mlp.hip)
+                nxt = None
+                if i + 1 < len(self.blocks):  # the next block's layer_norm1, on the rows while the kernel still holds them
+                    h_next = torch.empty((n * H * W, D), dtype=torch.float16, device=dev)
+                    nxt = (self.blocks[i + 1]["g1"], self.blocks[i + 1]["b1"], h_next)
+                K.ln_mlp(x, B["g2"], B["b2"], B["w1"], B["bb1"], B["w2"], B["bb2"], cfg.eps, x16=x16, next_ln=nxt)  # one pass over x (csrc/mlp.hip)
             else:
                 h2 = K.layernorm(x, B["g2"], B["b2"], cfg.eps)
                 u = K.gemm(h2, B["w1"], bias=B["bb1"], act=K.ACT_GELU)
