@@ -543,6 +543,24 @@ def _work(name, args):
     if name == "lmx_k_ln_mlp":
         rows, D = args[8], args[9]
         return "fused ln+mlp", 16.0 * D * D * rows, (16 + (2 if args[12] else 0) + (2 if args[15] else 0)) * D * rows, f"ln_mlp rows={rows} D={D}"
+    # streaming element-wise glue with a plain byte count: one HBM-bound class of its own (the rest — resizes, im2col, NMS,
+    # mask_post, contour features, decode — stays "pre/post-processing and glue": time share only)
+    if name == "lmx_k_cast_f32_f16":
+        rows, cols = args[4], args[5]
+        return "streaming glue", 0.0, 6 * rows * cols, f"cast_f32_f16 rows={rows} cols={cols}"
+    if name == "lmx_k_maxpool2":
+        dt, n_, H, W, C_ = args[4], args[5], args[6], args[7], args[8]
+        esz = 4 if dt == F32 else 2
+        return "streaming glue", 0.0, esz * n_ * H * W * C_ * 5 // 4, f"maxpool2 n={n_} H={H} W={W} C={C_} dtype={dt}"
+    if name == "lmx_k_upsample2":
+        n_, H, W, C_ = args[4], args[5], args[6], args[7]
+        return "streaming glue", 0.0, 2 * n_ * H * W * C_ * 5, f"upsample2 n={n_} H={H} W={W} C={C_}"
+    if name == "lmx_k_add_bcast":
+        a_dt, o_dt, rows, D = args[1], args[7], args[9], args[10]
+        return "streaming glue", 0.0, rows * D * ((4 if a_dt == F32 else 2) + (4 if o_dt == F32 else 2)), f"add_bcast rows={rows} D={D}"
+    if name == "lmx_k_rope":
+        B, T, H, hd = args[2], args[3], args[4], args[5]
+        return "streaming glue", 0.0, 2 * 2 * 2 * B * T * H * hd, f"rope B={B} T={T} H={H} hd={hd}"  # q and k, read + written, f16
     return "pre/post-processing and glue", 0.0, None, name
 
 
