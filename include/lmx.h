@@ -53,10 +53,10 @@ enum { LMX_ACT_NONE = 0, LMX_ACT_SILU = 1, LMX_ACT_GELU = 2 /* erf form */, LMX_
  *             Cin channels used): kernel 3x3, pad 1, stride conv_stride; M = n*Ho*Wo, K = 9*Cin,
  *             k = (ky*3+kx)*Cin + ci  (weights must be packed in that order).
  *   a_mode 2: "pooled rows" — A is a row-major [M][K] matrix whose rows are an [n][H][W_] token grid (H, W_ even), and C is
- *             the 2 x 2 max-pool of the product over that grid: f32 [M/4][N] in [n][H/2][W_/2] order, the bits of a_mode 0
+ *             the 2 x 2 max-pool of the product over that grid: [M/4][N] (f32 or f16) in [n][H/2][W_/2] order, the bits of a_mode 0
  *             followed by lmx_k_maxpool2 without the full-size intermediate (Hiera's `do_pool(self.proj(x))` at the stage
- *             transitions, TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock).  f32 out, no residual / scale /
- *             activation; M >= 512, N >= 96, N%8==0 (the LDS-DMA kernel); A smaller than 2 GB.
+ *             transitions, TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock, and of the pooled queries).  No
+ *             residual / scale / activation; M >= 512, N >= 96, N%8==0 (the LDS-DMA kernel); A smaller than 2 GB.
  * W is f16 [N][K] (K contiguous).  Requirements: K%8==0, N%4==0, lda%8==0, Cin%8==0, 16-byte aligned bases.
  */
 typedef struct {

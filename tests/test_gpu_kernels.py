@@ -81,6 +81,11 @@ def test_gemm_pooled_rows_equal_gemm_then_maxpool(cuda, n, H, W, K, N):
     got = Kk.gemm(a, w, bias=b, out_dtype=torch.float32, pool_hw=(H, W))
     assert got.shape == (M // 4, N)
     assert torch.equal(got, ref.view(-1, N))
+    # f16 output (Hiera's pooled queries): the f16 GEMM followed by the f16 max-pool
+    full16 = Kk.gemm(a, w, bias=b)
+    ref16 = torch.empty((n, H // 2, W // 2, N), dtype=torch.float16, device=cuda)
+    Kk.maxpool2(full16.view(n, H, W, N), ref16)
+    assert torch.equal(Kk.gemm(a, w, bias=b, pool_hw=(H, W)), ref16.view(-1, N))
     # and against plain fp32 arithmetic
     want = F.max_pool2d((a.float() @ w.float().t() + b).view(n, H, W, N).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).reshape(-1, N)
     _close(got, want, 2e-4, 1e-4, "pooled gemm")

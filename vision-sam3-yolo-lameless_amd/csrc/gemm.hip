@@ -286,7 +286,7 @@ extern "C" int lmx_k_gemm(const lmx_gemm_desc* dp, lmx_stream_t stream) {
     LMX_REQUIRE(d.lda >= d.K, "lmx_k_gemm: lda=%lld < K=%d", (long long)d.lda, d.K);
     LMX_REQUIRE(d.H > 0 && d.W_ > 0 && d.H % 2 == 0 && d.W_ % 2 == 0 && d.M % (d.H * d.W_) == 0,
                 "lmx_k_gemm: pooled rows need an even H x W token grid that divides M (H=%d W=%d M=%d)", d.H, d.W_, d.M);
-    LMX_REQUIRE(d.out_dtype == LMX_F32 && !d.res && !d.scale && d.act == LMX_ACT_NONE, "lmx_k_gemm: pooled rows: f32 out, no residual / scale / activation");
+    LMX_REQUIRE(!d.res && !d.scale && d.act == LMX_ACT_NONE, "lmx_k_gemm: pooled rows: no residual / scale / activation");
     LMX_REQUIRE(((int64_t)d.M * d.lda + d.K) * 2 < 0x7fffffffll, "lmx_k_gemm: pooled rows: A must be smaller than 2 GB");
     LMX_REQUIRE(d.M >= 512 && d.N >= 96 && d.N % 8 == 0 && d.ldc % 8 == 0 && aligned16(d.C),
                 "lmx_k_gemm: pooled rows are built for the LDS-DMA kernel (M >= 512, N >= 96, N %% 8 == 0): use GEMM + maxpool2 for M=%d N=%d", d.M, d.N);

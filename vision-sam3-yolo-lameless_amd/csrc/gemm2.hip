@@ -318,7 +318,27 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
       if constexpr (SCALE) v *= *reinterpret_cast<const f32x4*>(blj + BN + j * 16);
       return v;
     };
-    if constexpr (OUT_DT == LMX_F16) {
+    if constexpr (OUT_DT == LMX_F16 && AMODE == 2) {
+      // pooled rows, f16 out (Hiera's pooled queries): as the f32 form below, 8 bytes per lane
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v = finish(acc[pass][j], j);
+          // (the unfused path rounds to f16 first and pools the f16 values: rounding is monotonic, so max-then-round is the same)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = fmaxf(v[e], __shfl_xor(v[e], 1, 64));
+            v[e] = fmaxf(v[e], __shfl_xor(v[e], 2, 64));
+          }
+          const int m = m0 + wm * 64 + pass * 16 + frow;
+          const int n = n0 + wn * 64 + j * 16 + fq * 4;
+          if ((frow & 3) == 0 && m < p.M && n < p.N)
+            *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.C) + (int64_t)(m >> 2) * p.ldc + n) =
+                half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (OUT_DT == LMX_F16) {
       half_t* t16 = reinterpret_cast<half_t*>(my);
       constexpr int RS = 72;  // halfs per LDS row: 64 + 8 (16-byte pad keeps ds_read_b128 aligned and spreads banks)
 #pragma unroll

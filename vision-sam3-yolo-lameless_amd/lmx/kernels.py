@@ -59,7 +59,7 @@ def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtyp
     """out[M,N] = res + scale * act(a[M,K] @ w[N,K]^T + bias)   (lmx_k_gemm, a_mode 0).
     res_rows > 0: res is a [res_rows, N] table broadcast over the batch (row m uses res[m % res_rows]).
     pool_hw=(H, W): the rows of `a` are an [n, H, W] token grid and the result is the 2 x 2 max-pool of the product over that
-    grid, f32 [M/4, N] in [n, H/2, W/2] order (a_mode 2: the bits of gemm(...) followed by maxpool2, without the full-size
+    grid, [M/4, N] in [n, H/2, W/2] order (a_mode 2: the bits of gemm(...) followed by maxpool2, without the full-size
     intermediate)."""
     _dev(a, w, bias, scale, res, out)
     M, K, lda = _rows(a, "gemm A")
@@ -69,8 +69,6 @@ def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtyp
     if a.dtype != torch.float16 or w.dtype != torch.float16:
         raise LmxError("gemm: A and W must be float16")
     Mout = M // 4 if pool_hw else M
-    if pool_hw and (out_dtype != torch.float32 and out is None):
-        raise LmxError("gemm: pooled rows give float32")
     if out is None:
         out = torch.empty((Mout, N), dtype=out_dtype, device=a.device)
     Mo, No, ldc = _rows(out, "gemm C")

@@ -208,14 +208,22 @@ class HieraEncoder:
                 res = sc
             else:
                 res = x
-            qkv = K.gemm(h, B["wqkv"], bias=B["bqkv"])
-            q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             Hq, Wq = H, W
-            if qs:
+            if qs and K.pooled_gemm_ok(rows, D):
+                # pooled queries: the q third of the projection writes its 2 x 2 max-pool directly (a_mode 2), k and v come from
+                # a second launch on the same rows — the full-resolution q is neither written nor read back by a pooling pass
                 Hq, Wq = H // 2, W // 2
-                qp = torch.empty((n, Hq, Wq, D), dtype=torch.float16, device=dev)
-                K.maxpool2(qkv.view(n, H, W, 3 * D)[..., :D], qp)
-                q = qp.view(-1, D)
+                q = K.gemm(h, B["wqkv"][:D], bias=B["bqkv"][:D], pool_hw=(H, W))
+                kv = K.gemm(h, B["wqkv"][D:], bias=B["bqkv"][D:])
+                k, v = kv[:, :D], kv[:, D:]
+            else:
+                qkv = K.gemm(h, B["wqkv"], bias=B["bqkv"])
+                q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+                if qs:
+                    Hq, Wq = H // 2, W // 2
+                    qp = torch.empty((n, Hq, Wq, D), dtype=torch.float16, device=dev)
+                    K.maxpool2(qkv.view(n, H, W, 3 * D)[..., :D], qp)
+                    q = qp.view(-1, D)
             a = torch.empty((n * Hq * Wq, D), dtype=torch.float16, device=dev)
             if win > 0:
                 nW = -(-H // win) * -(-W // win)
