@@ -1,6 +1,7 @@
 // norm.hip — LayerNorm (K11), token assembly, token mean-pool (K22), DINOv3 RoPE.
 // All HBM-bound: one pass over the data, 16-byte lane accesses, wave-shuffle reductions, no LDS.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -106,6 +107,77 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     }
   }
 }
+
+// the same rows, several per wave: a wave walks rows w, w + W, ... and requests row r + W before it reduces row r (one row per
+// short-lived wave leaves the memory system waiting on wave launches: 4.7 TB/s on the f32 -> f16 LayerNorm of the ViT
+// blocks).  Same per-row arithmetic as layernorm_kernel: identical bits.
+template <int IN_DT, int OUT_DT, int ITERS>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const void* __restrict__ xv, int64_t ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, void* __restrict__ yv, int64_t ldy, int rows,
+                                                             int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nw = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 g[ITERS], b[ITERS];
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    g[i] = c < D ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    b[i] = c < D ? *reinterpret_cast<const f32x4*>(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto load = [&](int r, f32x4* v) {
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < D) {
+        if (IN_DT == LMX_F32) {
+          v[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(xv) + (int64_t)r * ldx + c);
+        } else {
+          const half4_t hv = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(xv) + (int64_t)r * ldx + c);
+          v[i] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        }
+      }
+    }
+  };
+  f32x4 v[ITERS], vn[ITERS];
+  load(row, v);
+  while (row < rows) {
+    const int nrow = row + nw;
+    if (nrow < rows) load(nrow, vn);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i)
+      if ((i * 64 + lane) * 4 < D) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i)
+      if ((i * 64 + lane) * 4 < D) {
+        const f32x4 dlt = v[i] - mean;
+        q += (dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3]);
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const f32x4 o = (v[i] - mean) * rstd * g[i] + b[i];
+        if (OUT_DT == LMX_F32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(yv) + (int64_t)row * ldy + c) = o;
+        } else {
+          const half4_t h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+          *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(yv) + (int64_t)row * ldy + c) = h;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) v[i] = vn[i];
+    row = nrow;
+  }
+}
+
 
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(const half_t* __restrict__ patch,
                                                               const float* __restrict__ prefix,
@@ -220,6 +292,17 @@ extern "C" int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const f
     return lmx_launch_check("layernorm_narrow_kernel");
   }
   dim3 grid((rows + 3) / 4), block(256);
+  // many rows of a ViT width, f32 stream -> f16: the several-rows-per-wave form (LMX_LN_ONE_ROW=1: the one-row-per-wave kernel)
+  static int one_row = -1;
+  if (one_row < 0) one_row = getenv("LMX_LN_ONE_ROW") ? 1 : 0;
+  if (!one_row && rows >= 16384 && act == LMX_ACT_NONE && in_dtype == LMX_F32 && out_dtype == LMX_F16 && D <= 1024) {
+    dim3 g2(256 * 8);  // eight workgroups of four waves per CU, each wave walking rows / 8192 rows
+    if (D <= 512)
+      hipLaunchKernelGGL((layernorm_rows_kernel<LMX_F32, LMX_F16, 2>), g2, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    else
+      hipLaunchKernelGGL((layernorm_rows_kernel<LMX_F32, LMX_F16, 4>), g2, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    return lmx_launch_check("layernorm_rows_kernel");
+  }
 #define LMX_LN(IN, OUT, IT) \
   hipLaunchKernelGGL((layernorm_kernel<IN, OUT, IT>), grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps, act)
 #define LMX_LN_IT(IN, OUT)        \
