@@ -9,8 +9,13 @@ and their copy to pinned host memory — what the services persist.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  `value` is the DENSE schedule (every frame through all
-three networks: the throughput mode); `reference_schedule` reports the services' own schedule (YOLO + SAM on frames
-0, 15, ..., 135, DINO on 0, 30, ..., 120: yolo main.py:67, dinov3 main.py:127) on the same clip.  `roofline` is the kernel class
+three networks: the throughput mode, YOLO on its f16 plan); `reference_schedule` reports the services' own schedule (YOLO +
+SAM on frames 0, 15, ..., 135, DINO on 0, 30, ..., 120: yolo main.py:67, dinov3 main.py:127) on the same clip with YOLO on its
+EXACT plan (keep-sets of the fp32 path: the mode whose JSON must match).
+With N > 1 ranks the headline is the path north_star describes — ONE 150-frame clip per step, rank r runs its contiguous block
+of ceil(150 / N) frames, one gather of the packed records to rank 0, D2H there (`"scaling": "strong"`) — and the clip-per-GPU
+rate (`"weak_scaling"`: every rank its own clip, the round-1/2 definition) is reported beside it; `--clip-per-gpu` makes the
+weak form the headline.  `per_config` holds standalone rates of BASELINE cfg#2 / #3 / #4 at their stated shapes.  `roofline` is the kernel class
 with the largest share of GPU time, `roofline_classes` lists every class — each timed live with HIP events on the launch
 stream during K more serialized steps, bound chosen by arithmetic intensity; `cpu_baseline` is the fp32 oracle on the host.
 """
@@ -51,7 +56,7 @@ def cpu_baseline(n_frames, clip_seed):
         share = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(share, torch.get_num_threads(), 16)))
     ycfg, scfg, dcfg = yolo.YoloConfig("l"), sam.hiera_b_plus(), dino.dinov3_vitl16()
-    bn = os.path.join(ROOT, "tests", "golden", "yolov8l_bn_w7.npz")
+    bn = yolo.bn_stats_path("l")
     ysd = yolo.synthetic_state_dict(ycfg, 7, bn)
     ssd = weights.synth_state_dict(sam.param_spec(scfg), 5)
     dsd = weights.synth_state_dict(dino.param_spec(dcfg), 3)
@@ -134,17 +139,80 @@ def roofline_classes(trace, wall_s):
     return out, total / wall_s if wall_s > 0 else None
 
 
+def per_config_rates(fx, dev, rank, world, log, dist):
+    """Standalone throughput of BASELINE cfg#2 / cfg#3 / cfg#4 at their stated shapes, a few passes each,
+    inputs resident in HBM: frames/s per GPU, algorithmic TFLOP/s and the fraction of the dense f16 MFMA peak (all three are
+    MFMA-bound by arithmetic intensity).  cfg#4's 256 frames are sharded over the ranks and the [256, 1024] embeddings
+    all-gathered, as the config words it; cfg#2 / cfg#3 run the same batch on every rank (rank 0's rate is reported)."""
+    from lmx import dist as ldist
+    from lmx import synth
+
+    def rate(fn, n_img, gflop_per_img, iters=4, sync_all=False):
+        fn()
+        torch.cuda.synchronize()
+        if world > 1 and sync_all:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1 and sync_all:
+            dist.barrier()
+        dt = (time.perf_counter() - t0) / iters
+        tf = n_img * gflop_per_img / dt / 1e3
+        return {"frames_per_s": n_img / dt, "ms_per_batch": dt * 1e3, "tflops": tf, "frac_of_mfma_peak": tf / PEAK_F16_TFLOPS}
+
+    out = {}
+    f2 = torch.from_numpy(synth.cfg2_frames()).to(dev)
+    out["cfg2_yolov8l_640x640_b32"] = dict(rate(lambda: fx.yolo.detect(f2, conf=0.25, precision="f16"), 32, 165.1),
+                                           plan="f16 (throughput)", gflop_per_img=165.1, per="GPU")
+    out["cfg2_yolov8l_640x640_b32_exact"] = dict(rate(lambda: fx.yolo.detect(f2, conf=0.25, precision="exact"), 32, 165.1, iters=2),
+                                                 plan="exact (fp32 keep-sets; 3x the MFMA work, tflops counts the fp32-equivalent work)",
+                                                 gflop_per_img=165.1, per="GPU")
+    del f2
+    log("per_config: cfg#2 done")
+    f3 = torch.from_numpy(np.stack([synth.synth_frame(2, i, 1024, 1024) for i in range(16)], 0)).to(dev)
+    out["cfg3_hiera_bplus_1024_b16"] = dict(rate(lambda: fx.sam.encode(f3), 16, 645.0), gflop_per_img=645.0, per="GPU")
+    del f3
+    log("per_config: cfg#3 done")
+    lo, hi = ldist.shard_range(256, rank, world)
+    f4 = torch.from_numpy(np.stack([synth.synth_frame(21, i % 16) for i in range(lo, hi)], 0)).to(dev) if hi > lo else None
+    D = fx.dino.cfg.hidden
+    rows = ldist.shard_rows(256, world)
+
+    def cfg4():
+        e = torch.zeros((rows, D), dtype=torch.float32, device=dev)
+        if f4 is not None:
+            e[:hi - lo] = fx.dino.embed_frames(f4)
+        if world > 1:
+            g = torch.empty((world * rows, D), dtype=torch.float32, device="cpu" if dist.get_backend() == "gloo" else dev)
+            dist.all_gather_into_tensor(g, e.cpu() if dist.get_backend() == "gloo" else e)
+        return e
+
+    out["cfg4_dinov3_vitl16_224_b256"] = dict(rate(cfg4, 256, 125.7, sync_all=True), gflop_per_img=125.7, per="whole job",
+                                              parallelism=f"256 frames sharded over {world} rank(s), all-gather of [256, {D}] f32",
+                                              input="raw 1080p frames (Pillow-exact bicubic resize + crop + patchify on the device included)")
+    if world > 1:
+        out["cfg4_dinov3_vitl16_224_b256"]["frac_of_mfma_peak"] /= world
+    log("per_config: cfg#4 done")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=150, help="frames of the synthetic clip per GPU per step (5 s @ 30 fps = 150)")
+    ap.add_argument("--frames", type=int, default=150, help="frames of the synthetic clip per step (5 s @ 30 fps = 150)")
     ap.add_argument("--fps", type=int, default=30)
     ap.add_argument("--sam-chunk", type=int, default=30, help="frames per SAM encoder pass (each pass runs on its own HIP stream; 150 = 5 x 30)")
+    ap.add_argument("--shard-sam-chunk", type=int, default=0, help="frames per SAM pass of a rank's block in the sharded-clip step (0: ceil(block / 2))")
+    ap.add_argument("--clip-per-gpu", action="store_true", help="N > 1: make the clip-per-GPU (weak) rate the headline instead of the sharded clip")
+    ap.add_argument("--shard-clip", action="store_true", help="N > 1: sharded clip as the headline (the default; kept for explicitness)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-schedule", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-per-config", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--shapes-out", default=None, help="write the per-shape table of the roofline leg (text) to this file")
     args = ap.parse_args()
@@ -163,6 +231,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -183,7 +252,7 @@ def main():
     log("building synthetic weights")
     fx = pipeline.FusedExtractor(dev)
     log(f"generating the synthetic clip ({args.frames} unique 1080p frames per rank)")
-    # weak scaling: every rank owns one clip (seed = 100 + rank); frames are unique within the clip
+    # clip-per-GPU (weak) form: every rank owns one clip (seed = 100 + rank); frames are unique within the clip
     host = synth.synth_clip(100 + rank, args.frames)
     frames = torch.from_numpy(host).to(dev)
     del host
@@ -192,7 +261,19 @@ def main():
     sched_frames = frames[sched].contiguous()
     det_idx = [j for j, i in enumerate(sched) if i % i_det == 0]
     emb_idx = [j for j, i in enumerate(sched) if i % i_emb == 0]
+    # sharded-clip (strong) form: ONE clip (seed 100) per step, rank r keeps the frames of its contiguous block
+    lo, hi = ldist.shard_range(args.frames, rank, world)
+    shard = None
+    if world > 1:
+        shard = frames[lo:hi] if rank == 0 else torch.from_numpy(synth.synth_clip(100, hi - lo, start=lo)).to(dev) if hi > lo else frames[:0]
+    shard_chunk = args.shard_sam_chunk or max(1, -(-(hi - lo) // 2))
     pinned = {}
+
+    def to_host(buf):
+        key = tuple(buf.shape)
+        if key not in pinned:
+            pinned[key] = torch.empty(buf.shape, dtype=torch.uint8).pin_memory()
+        pinned[key].copy_(buf, non_blocking=True)
 
     def persist(out):
         """What leaves the GPU per clip: ONE packed record buffer -> (one gather to rank 0) -> pinned host memory."""
@@ -209,16 +290,24 @@ def main():
                 buf = ldist.gather_packed(buf, root=None)
                 if rank != 0:
                     return
-        key = tuple(buf.shape)
-        if key not in pinned:
-            pinned[key] = torch.empty(buf.shape, dtype=torch.uint8).pin_memory()
-        pinned[key].copy_(buf, non_blocking=True)
+        to_host(buf)
 
+    # the dense schedule is the THROUGHPUT mode: YOLO on its f16 plan; the reference schedule is the mode whose JSON must match
+    # the reference: YOLO on its exact plan (lmx.yolo.YoloDetector)
     def step_dense():
-        persist(fx.step(frames, sam_chunk=args.sam_chunk))
+        persist(fx.step(frames, sam_chunk=args.sam_chunk, yolo_precision="f16"))
 
     def step_reference():
-        persist(fx.step(sched_frames, sam_chunk=args.sam_chunk, det_idx=det_idx, emb_idx=emb_idx))
+        persist(fx.step(sched_frames, sam_chunk=args.sam_chunk, det_idx=det_idx, emb_idx=emb_idx, yolo_precision="exact"))
+
+    def step_sharded():
+        """north_star's multi-GPU path: this rank's block of THE clip, then ONE gather of the packed records to rank 0 (the
+        service's collective: lmx.dist.gather_clip_records pads the short last blocks), D2H on rank 0."""
+        out = {k: v for k, v in fx.step(shard, sam_chunk=shard_chunk, yolo_precision="f16").items() if k != "mask"}
+        buf, _ = ldist.pack_records(out, ldist.shard_rows(args.frames, world))
+        g = ldist.gather_packed(buf, root=0)
+        if g is not None:
+            to_host(g)
 
     def timed(step, label):
         for i in range(args.warmup):
@@ -242,22 +331,25 @@ def main():
         log(f"{label}: {args.steps} steps in {dt:.3f}s")
         return dt
 
-    dt = timed(step_dense, "dense schedule")
+    strong = world > 1 and not args.clip_per_gpu
+    dt_shard = timed(step_sharded, "sharded clip (one clip per step over all ranks)") if world > 1 else None
+    dt_dense = timed(step_dense, "dense schedule, one clip per GPU")
+    dt = dt_shard if strong else dt_dense
     dt_ref = None if args.no_reference_schedule else timed(step_reference, "reference schedule")
 
-    # Roofline leg: the timed steps keep up to six HIP streams in flight, so an event pair around one launch would time its
+    # Roofline leg: the timed steps keep up to seven HIP streams in flight, so an event pair around one launch would time its
     # neighbours too.  Every launch is therefore bracketed on K more steps of the SAME workload run on one stream (not part
     # of `value`); rocprofv3's per-kernel averages in profiles/ are taken the same way (LMX_SERIAL=1).
     # (every rank replays, without collectives; rank 0 reports)
     classes, traced_share, dt_serial = None, None, None
     if not args.no_roofline:
         fx.serial = True
-        fx.step(frames, sam_chunk=args.sam_chunk)
+        fx.step(frames, sam_chunk=args.sam_chunk, yolo_precision="f16")
         torch.cuda.synchronize()
         K.start_launch_trace()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            fx.step(frames, sam_chunk=args.sam_chunk)
+            fx.step(frames, sam_chunk=args.sam_chunk, yolo_precision="f16")
         torch.cuda.synchronize()
         dt_serial = time.perf_counter() - t1
         trace, shapes = K.stop_launch_trace(by_shape=True)
@@ -274,34 +366,50 @@ def main():
             c["launches_per_step"] = c.pop("launches") // max(args.steps, 1)
         log(f"roofline pass: {args.steps} serialized steps in {dt_serial:.3f}s")
 
+    per_config = None if args.no_per_config else per_config_rates(fx, dev, rank, world, log, dist)
+
     if rank == 0:
-        total_frames = args.frames * world * args.steps
+        job_frames = args.frames * args.steps * (1 if strong else world)
+        workload = ("BASELINE cfg#5, dense schedule: fused per-frame path on a synthetic 5 s @ 30 fps 1080p clip (150 unique BGR "
+                    "frames resident in HBM): YOLOv8-l detect (letterbox 384x640, NMS, scale_boxes; f16 plan) -> SAM (Hiera-B+ image "
+                    "encoder + FPN at 1024x1024, box-prompted mask decoder, 1080p mask + statistics + contour features) + DINOv3 "
+                    "ViT-L/16 embed (224x224) on EVERY frame; per-frame records packed, gathered to rank 0 and copied to pinned "
+                    "host memory inside the step; synthetic weights")
         line = {
             "metric": "frames/sec (whole node) for YOLO+SAM3+DINOv3 feature extraction, 1080p clips",
-            "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": job_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg#5, dense schedule: fused per-frame path on one synthetic 5 s @ 30 fps 1080p clip per GPU "
-                                   "and step (150 unique BGR frames resident in HBM): YOLOv8-l detect (letterbox 384x640, NMS, scale_boxes) "
-                                   "-> SAM (Hiera-B+ image encoder + FPN at 1024x1024, box-prompted mask decoder, 1080p mask + statistics) "
-                                   "+ DINOv3 ViT-L/16 embed (224x224) on EVERY frame; per-frame records packed, gathered to rank 0 and "
-                                   "copied to pinned host memory inside the step; synthetic weights",
-                       "frames_per_gpu_per_step": args.frames, "parallelism": f"one clip per GPU, {world} GPU(s), one gather per step",
+            "config": {"workload": workload,
+                       "frames_per_step": args.frames if strong else args.frames * world,
+                       "frames_per_gpu_per_step": (hi - lo) if strong else args.frames,
+                       "parallelism": (f"ONE clip per step sharded over {world} GPUs in contiguous blocks of {ldist.shard_rows(args.frames, world)} "
+                                       f"frames, one gather of the packed records to rank 0 per step (SAM passes of {shard_chunk} frames)"
+                                       if strong else f"one clip per GPU, {world} GPU(s), one gather per step"),
                        "gflop_per_frame": sum(GFLOP_PER_FRAME.values()), "streams": fx.max_streams},
         }
+        if world > 1:
+            line["weak_scaling"] = {"value": args.frames * world * args.steps / dt_dense, "unit": "frames/s", "ms_per_step": dt_dense / args.steps * 1e3,
+                                    "note": "every rank its own 150-frame clip per step (per-GPU work fixed), one all-gather of the records per step"}
+            line["sharded_clip"] = {"value": args.frames * args.steps / dt_shard, "unit": "frames/s", "ms_per_step": dt_shard / args.steps * 1e3,
+                                    "frames_per_gpu_per_step": ldist.shard_rows(args.frames, world), "sam_chunk": shard_chunk,
+                                    "note": "north_star's path: decoded frames of ONE clip shard across the GPUs, RCCL gather only to reassemble per-clip outputs"}
         if dt_ref is not None:
             line["reference_schedule"] = {
-                "value": total_frames / dt_ref, "unit": "clip frames/s", "ms_per_clip": dt_ref / args.steps * 1e3,
-                "network_passes_per_clip": {"yolo+sam": len(det_idx), "dino": len(emb_idx)},
+                "value": args.frames * world * args.steps / dt_ref, "unit": "clip frames/s", "ms_per_clip": dt_ref / args.steps * 1e3,
+                "network_passes_per_clip": {"yolo+sam": len(det_idx), "dino": len(emb_idx)}, "yolo_plan": "exact",
                 "note": "the services' own sampling (yolo main.py:67, dinov3 main.py:127): YOLO+SAM on frames 0,15,..,135, DINO on 0,30,..,120 "
-                        "of the same clip; the mode whose JSON matches the reference"}
+                        "of the same clip (one clip per GPU); the mode whose JSON matches the reference: YOLO on its exact plan "
+                        "(keep-sets identical to the fp32 path)"}
         if classes:
             modelled = [c for c in classes if c["bound"]]
             head = max(modelled, key=lambda c: c["time_share"])
-            line["roofline"] = dict(head, measured_on=f"the same steps replayed on one HIP stream after the timed region "
+            line["roofline"] = dict(head, measured_on=f"the dense clip-per-GPU steps replayed on one HIP stream after the timed region "
                                                       f"({dt_serial / args.steps * 1e3:.1f} ms/step serialized; events cover "
                                                       f"{100 * traced_share:.0f} % of it)")
             line["roofline_classes"] = classes
+        if per_config:
+            line["per_config"] = per_config
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames, 100)
         print(json.dumps(line), flush=True)

@@ -223,6 +223,26 @@ int lmx_k_detect_decode(const float* head, int64_t ldh, float* pred, int n, int 
 int lmx_k_scale_boxes(float* boxes, int total, float padx, float pady, float gain, float w, float h,
                       lmx_stream_t stream);
 
+/* ---- EXACT-precision plan of the YOLO conv stack (lmx/yolo.py precision="exact"; csrc/exact.hip) -------------------------
+ * north_star asks for NMS keep-sets bit-exact against the fp32 CPU path of yolo main.py:76; f16 activations deviate 3e-3 in
+ * score.  The exact plan keeps lmx_k_gemm and feeds it operands with 22 mantissa bits: a value x travels as the f16 channel
+ * triple [hi | lo | hi] per channel group of width g ("x3": hi = f16(x), lo = f16((x - hi) * 2048)), a weight row as
+ * [whi | whi/2048 | wlo] over the same groups (rows pre-scaled by a power of two, undone by lmx_k_gemm's `scale`), so ONE
+ * lmx_k_gemm launch over K' = 3K with f32 output yields x.w up to the dropped (x-hi)(w-whi) term (2^-22 relative).
+ * lmx_k_split3: y = act(x) (+ the value of the x3 residual res3), written as x3 groups: f32 x [rows][ldx], N logical
+ *   channels in groups of g (N % g == 0, g % 8 == 0): logical channel n = q*g + r sits at out3[m*ldo + q*3g + r] (hi),
+ *   + g (lo), + 2g (hi again); res3 has the same grouping with pixel stride ldr.  act: NONE / SILU / RELU, SiLU as
+ *   x / (1 + exp(-x)) with a true division (torch's CPU form).  Replaces the activation half of ultralytics' Conv and the
+ *   shortcut add of Bottleneck under the exact plan.
+ * lmx_k_maxpool5_x3: lmx_k_maxpool5 on an x3 slice of C logical channels (maximum by value; the pair travels with it).
+ * lmx_k_stem_conv_x3: lmx_k_stem_conv writing x3: out3 f16 [n][H/2][W/2][3*Cout].
+ * (nearest upsampling of an x3 slice is lmx_k_upsample2 over 3C channels.) */
+int lmx_k_split3(const float* x, int64_t ldx, int act, const void* res3, int64_t ldr, void* out3, int64_t ldo, int64_t rows,
+                 int N, int g, lmx_stream_t stream);
+int lmx_k_maxpool5_x3(const void* src3, int64_t lds, void* dst3, int64_t ldd, int n, int H, int W, int C, lmx_stream_t stream);
+int lmx_k_stem_conv_x3(const uint8_t* img, const float* w, const float* bias, void* out3, int n, int H, int W, int Cout,
+                       lmx_stream_t stream);
+
 /* Pose head post-processing for the detections lmx_k_nms kept (ultralytics Pose.kpts_decode + ops.scale_coords +
  * clip_coords; the YOLOv8-pose consumer is services/tleap-pipeline/app/main.py:142-163, `result.keypoints[j].data`).
  * raw0..2: the three levels' cv4 outputs, f32 [n][h_l][w_l][ldk] (ldk >= K*ndim); hw = {h0,w0,h1,w1,h2,w2} and strides[3]

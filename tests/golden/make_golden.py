@@ -78,7 +78,7 @@ def make_yolo(scale, seed, calib_clip, frames_spec):
     x = torch.stack([torch.from_numpy(np.ascontiguousarray(OY.letterbox(f)[:, :, ::-1].transpose(2, 0, 1))).float() / 255
                      for f in calib])
     stats = OY.calibrate_bn(scale, cfg.nc, sd, x)
-    bn_path = os.path.join(HERE, f"yolov8{scale}_bn_w{seed}.npz")
+    bn_path = yolo.bn_stats_path(scale, seed)
     np.savez(bn_path, **stats)
     sd = yolo.synthetic_state_dict(cfg, seed, bn_path)
     out = {"weight_seed": seed, "frames": np.asarray(frames_spec)}
@@ -105,7 +105,7 @@ def make_yolo_pose(scale, seed, calib_clip, frames_spec, kpt_shape=(17, 3), conf
     x = torch.stack([torch.from_numpy(np.ascontiguousarray(OY.letterbox(f)[:, :, ::-1].transpose(2, 0, 1))).float() / 255
                      for f in calib])
     stats = OY.calibrate_bn(scale, cfg.nc, sd, x, kpt_shape=kpt_shape)
-    bn_path = os.path.join(HERE, f"yolov8{scale}-pose_bn_w{seed}.npz")
+    bn_path = yolo.bn_stats_path(scale, seed, pose=True)
     np.savez(bn_path, **stats)
     sd = yolo.synthetic_state_dict(cfg, seed, bn_path)
     out = {"weight_seed": seed, "frames": np.asarray(frames_spec), "conf": conf}
@@ -138,6 +138,21 @@ def make_hiera(seed, clip_seed, frame_ids):
     print("hiera-b+ golden:", [tuple(f.shape) for f in fpn], "rms fpn2", float(fpn[2].pow(2).mean().sqrt()))
 
 
+def make_cfg1(scale="n", seed=7, conf=0.001):
+    """BASELINE cfg#1: services/yolo-pipeline on ONE 640 x 640 frame presented as a 1-frame clip, YOLOv8-n,
+    conf lowered to 0.001 so that NMS and the max_det = 300 cut are exercised; the fp32 oracle's kept detections."""
+    from lmx import synth, yolo
+    from oracle import yolo as OY
+
+    cfg = yolo.YoloConfig(scale)
+    sd = yolo.synthetic_state_dict(cfg, seed, yolo.bn_stats_path(scale, seed))
+    frame = synth.cfg1_frame()
+    r = OY.predict(scale, cfg.nc, sd, frame, conf=conf)
+    print(f"cfg1 yolov8{scale}: {len(r['src'])} detections at conf {conf}, scores {r['scores'][:3]} .. {r['scores'][-3:]}")
+    np.savez_compressed(os.path.join(HERE, f"cfg1_yolov8{scale}_w{seed}.npz"), weight_seed=seed, conf=conf, boxes=r["boxes"],
+                        scores=r["scores"], cls=r["cls"], src=r["src"], pred_sample=r["pred"][::97])
+
+
 def make_yolo_cfg2(scale="l", seed=7, frame_ids=(0, 31)):
     """fp32 oracle detections for two frames of the cfg#2 batch (YOLOv8-l, 640x640, batch 32).  Weights: seed 7 with the
     committed BatchNorm statistics (SURVEY names seed 1; the calibrated statistics exist for seed 7 — same architecture)."""
@@ -145,7 +160,7 @@ def make_yolo_cfg2(scale="l", seed=7, frame_ids=(0, 31)):
     from oracle import yolo as OY
 
     cfg = yolo.YoloConfig(scale)
-    sd = yolo.synthetic_state_dict(cfg, seed, os.path.join(HERE, f"yolov8{scale}_bn_w{seed}.npz"))
+    sd = yolo.synthetic_state_dict(cfg, seed, yolo.bn_stats_path(scale, seed))
     fr = synth.cfg2_frames()
     out = {"weight_seed": seed, "frame_ids": np.asarray(frame_ids)}
     for j, fi in enumerate(frame_ids):
@@ -211,6 +226,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cfg2":
         make_yolo_cfg2()
+        make_cfg1()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg1":
+        make_cfg1()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sam_masks":
         make_sam_masks("hiera_bplus", 5)
@@ -227,5 +246,6 @@ if __name__ == "__main__":
     make_dino("dinov2_base_w4", dino.dinov2_base(), 4, [0, 30], clip_seed=5)
     make_hiera(5, 6, [20])
     make_yolo_cfg2()
+    make_cfg1()
     make_sam_masks("hiera_bplus", 5)
     make_sam_masks("vit_b", 9)

@@ -189,3 +189,50 @@ def test_fused_service_world2_equals_world1(tmp_path, schedule, n_frames):
         assert a == b, f"{key} JSON differs between world 1 and world 2"
         assert not (tmp_path / "w2r1" / sub / f"z_{key}.json").exists()
     assert json.loads(a)["num_embeddings"] == len(range(0, n_frames, 30))
+
+
+def _worker_failing_rank(rank, world, port, q, root_dir, clip_path, how):
+    """One rank's local pass fails (extractor raises / its clip is missing); both ranks must come back."""
+    sys.path.insert(0, HERE)
+    import asyncio
+    import time
+    from pathlib import Path
+
+    import test_services_host as H
+    from lmx.services import runtime as R
+
+    _init(rank, world, port)
+    try:
+        calls = _count_collectives()
+        bus = R.InProcessBus()
+        per_frame = (lambda fid: [([2 + fid % 5, 2, 20 + fid % 7, 22], 0.9, 19)])
+        _, _, _, fused, fx = H._three_and_fused(Path(root_dir), f"fail_{how}_r{rank}", bus, per_frame, "reference", chunk=3)
+        path = clip_path
+        if rank == 1 and how == "raise":
+            def boom(*a, **k):
+                raise RuntimeError("injected failure on rank 1")
+            fx.step = boom
+        if rank == 1 and how == "missing":
+            path = clip_path + ".not_on_this_rank"
+        t0 = time.time()
+        asyncio.run(fused.process_video({"video_id": "z", "processed_path": path, "filename": "z.mp4"}))
+        q.put((rank, [p[0] for p in bus.published], list(calls), time.time() - t0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("how", ["raise", "missing"])
+def test_fused_service_world2_failing_rank_does_not_hang(tmp_path, how):
+    """A rank whose local pass fails (exception in the extractor, or the clip missing on its filesystem) still joins the
+    control all-reduce, which carries an error flag: BOTH ranks skip the gather together, return within the timeout, and
+    nothing is written or published — the single-process error convention (yolo main.py:203-206)."""
+    sys.path.insert(0, HERE)
+    import test_services_host as H
+
+    clip = H._clip(tmp_path, 64, 30.0)
+    res = _spawn(_worker_failing_rank, 2, str(tmp_path), str(clip), how)  # _spawn's q.get(timeout) is the hang detector
+    for rank, published, calls, secs in res:
+        assert published == [], f"rank {rank} published {published} although a rank failed"
+        assert "gather" not in calls and calls.count("all_reduce") <= 1, calls
+        assert secs < 60
+    assert not list(tmp_path.glob("fail_*/*/z_*.json"))

@@ -17,7 +17,7 @@ def test_yolo_adapter_reference_idiom(cuda, tmp_path):
     from lmx import adapters, checkpoints, synth, yolo
 
     cfg = yolo.YoloConfig("n")
-    sd = yolo.synthetic_state_dict(cfg, 7, "tests/golden/yolov8n_bn_w7.npz")
+    sd = yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path("n"))
     d = tmp_path / "models" / "yolo"
     d.mkdir(parents=True)
     save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, str(d / "cow_detector.safetensors"))
@@ -61,7 +61,7 @@ def test_yolo_pose_adapter_tleap_idiom(cuda):
     from lmx import adapters, synth, yolo
 
     cfg = yolo.YoloConfig("n", nc=1, kpt_shape=(17, 3))
-    sd = yolo.synthetic_state_dict(cfg, 7, "tests/golden/yolov8n-pose_bn_w7.npz")
+    sd = yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path("n", pose=True))
     model = adapters.LmxYolo((cfg, sd), device=cuda)
     frame = synth.synth_frame(3, 40)
     # tleap main.py:142-163

@@ -28,7 +28,7 @@ def test_fused_service_end_to_end(cuda, tmp_path):
     R.save_npz_clip(clip, frames, 8.0)  # YOLO/SAM: frames 0,4,8; DINO: frames 0,8
     # backends: YOLOv8-n, a narrow Hiera (same block structure, 1024^2 input, 256-d FPN) + the SAM decoder, a small DINOv3
     ycfg = yolo.YoloConfig("n")
-    ysd = yolo.synthetic_state_dict(ycfg, 7, os.path.join(GOLD, "yolov8n_bn_w7.npz"))
+    ysd = yolo.synthetic_state_dict(ycfg, 7, yolo.bn_stats_path("n"))
     hcfg = sam.HieraConfig(hidden=16, blocks=(1, 2, 3, 2), dims=(16, 32, 64, 128), heads=(1, 2, 4, 8), global_blocks=(4,),
                            pos_bkg=(7, 7), fpn_dim=256, image=1024)
     hsd = weights.synth_state_dict(sam.param_spec(hcfg), 51)
@@ -118,7 +118,7 @@ def test_tleap_pose_estimator_surface(cuda):
     from lmx.services import PoseEstimator
     from lmx.services.pose import KEYPOINT_NAMES
 
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolov8n-pose_bn_w7.npz")
+    gold = yolo.bn_stats_path("n", pose=True)
     cfg = yolo.YoloConfig("n", nc=1, kpt_shape=(17, 3))
     det = yolo.YoloDetector(cfg, yolo.synthetic_state_dict(cfg, 7, gold), cuda)
     est = PoseEstimator(det, conf=0.05)
@@ -143,7 +143,7 @@ def test_clip_curation_tracker(cuda):
     from lmx.services import CowTracker
     from lmx.services.curation import best_detection
 
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolov8n_bn_w7.npz")
+    gold = yolo.bn_stats_path("n")
     cfg = yolo.YoloConfig("n")
     det = yolo.YoloDetector(cfg, yolo.synthetic_state_dict(cfg, 7, gold), cuda)
     frames = torch.from_numpy(np.stack([synth.synth_frame(3, i) for i in (40, 41, 42)], 0)).to(cuda)

@@ -1,9 +1,10 @@
 """GPU parity of the YOLO path (services/yolo-pipeline/app/main.py:76) through the C-ABI.
   * byte/index kernels (letterbox, max-pool, upsample, NMS on a given prediction tensor): bit-exact;
-  * the conv stack runs in f16 with f32 accumulation against an fp32 oracle: the raw prediction tensor must agree to
-    f16-rounding level, and the kept detections must agree except where a score or IoU lies within the stated margin
-    of a threshold (BASELINE.json asks for bit-exact keep-sets; an f16 network cannot promise that for borderline
-    candidates, so borderline cases are COUNTED and bounded, never silently accepted — see DESIGN.md §parity)."""
+  * EXACT plan (lmx.yolo precision="exact": what the services, the adapters and the reference schedule run): the prediction
+    tensor agrees with the fp32 oracle to fp32 rounding level (scores <= 1e-5) and the NMS keep-sets / box indices / classes
+    are IDENTICAL to the committed fp32 goldens — np.array_equal, no margin rule (north_star: bit-exact keep-sets);
+  * F16 plan (the dense THROUGHPUT schedule only): f16 activations deviate 3e-3 .. 6e-3 in score from fp32, so its keep-sets
+    are held to the margin rule of tests/keepset.py (borderline candidates counted and bounded) — labelled as such."""
 import os
 
 import numpy as np
@@ -82,15 +83,17 @@ def test_stem_pool_upsample_decode(cuda):
 
 
 @pytest.mark.parametrize("scale,frames", [("n", [(3, 40), (2, 50), (4, 0)]), ("l", [(3, 40), (2, 50)])])
-def test_yolo_end_to_end(cuda, scale, frames):
+def test_yolo_f16_plan_margin_rule(cuda, scale, frames):
+    """The dense throughput plan (precision="f16") against the fp32 oracle: margin rule, NOT the drop-in parity bar (that is
+    test_yolo_exact_plan_keepsets_equal_fp32 below)."""
     from lmx import kernels as K
     from lmx import synth, yolo
     from oracle import nms as ONMS
     from oracle import yolo as OY
 
     cfg = yolo.YoloConfig(scale)
-    sd = yolo.synthetic_state_dict(cfg, 7, os.path.join(GOLD, f"yolov8{scale}_bn_w7.npz"))
-    det = yolo.YoloDetector(cfg, sd, cuda)
+    sd = yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path(scale))
+    det = yolo.YoloDetector(cfg, sd, cuda, precision="f16")
     gold = np.load(os.path.join(GOLD, f"yolov8{scale}_det_w7.npz"))
     fr = np.stack([synth.synth_frame(cs, fi) for cs, fi in frames], 0)
     d_fr = torch.from_numpy(fr).to(cuda)
@@ -200,8 +203,8 @@ def test_pose_end_to_end(cuda):
 
     kshape = (17, 3)
     cfg = yolo.YoloConfig("n", nc=1, kpt_shape=kshape)
-    sd = yolo.synthetic_state_dict(cfg, 7, os.path.join(GOLD, "yolov8n-pose_bn_w7.npz"))
-    det = yolo.YoloDetector(cfg, sd, cuda)
+    sd = yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path("n", pose=True))
+    det = yolo.YoloDetector(cfg, sd, cuda, precision="f16")
     gold = np.load(os.path.join(GOLD, "yolov8n-pose_det_w7.npz"))
     conf = float(gold["conf"])
     fr = np.stack([synth.synth_frame(int(cs), int(fi)) for cs, fi in gold["frames"]], 0)
@@ -243,7 +246,7 @@ def test_pose_end_to_end(cuda):
 
 
 def test_cfg2_yolov8l_640x640_batch32(cuda):
-    """BASELINE cfg#2: YOLOv8-l on [32,640,640,3] (no letterbox padding: 640x640 frames map 1:1).  The two golden frames
+    """BASELINE cfg#2 on the throughput (f16) plan: YOLOv8-l on [32,640,640,3] (no letterbox padding: 640x640 frames map 1:1).  The two golden frames
     (indices 0 and 31 of the batch) pass the keep-set margin rule against the committed fp32 oracle prediction; NMS on the
     device prediction is bit-exact against the oracle NMS for every frame of the batch; a second run of the whole batch is
     bit-identical; frames of the batch do not influence each other (frame 31 alone == frame 31 in the batch)."""
@@ -253,8 +256,8 @@ def test_cfg2_yolov8l_640x640_batch32(cuda):
 
     g = np.load(os.path.join(GOLD, "yolov8l_cfg2_w7.npz"))
     cfg = yolo.YoloConfig("l")
-    sd = yolo.synthetic_state_dict(cfg, int(g["weight_seed"]), os.path.join(GOLD, "yolov8l_bn_w7.npz"))
-    det = yolo.YoloDetector(cfg, sd, cuda)
+    sd = yolo.synthetic_state_dict(cfg, int(g["weight_seed"]), yolo.bn_stats_path("l"))
+    det = yolo.YoloDetector(cfg, sd, cuda, precision="f16")
     fr = synth.cfg2_frames()
     assert fr.shape == (32, 640, 640, 3)
     d_fr = torch.from_numpy(fr).to(cuda)
@@ -297,3 +300,103 @@ def test_cfg2_yolov8l_640x640_batch32(cuda):
     b, s, c, src, cnt = (t.cpu().numpy() for t in K.nms(pred, 0.5))
     assert np.array_equal(counts.cpu().numpy(), cnt) and np.array_equal(src2.cpu().numpy(), src)
     assert np.allclose(boxes.cpu().numpy(), np.clip(b, 0, 640), atol=1e-4)  # gain 1, no padding: scale_boxes only clips
+
+
+# ---- the EXACT plan: keep-sets identical to the fp32 goldens (north_star) -------------------------------------------------------
+EXACT_SCORE_EPS = 2e-5   # measured on MI355X: <= 1.01e-5 over every kept detection (yolov8l), 4e-6 on the prediction sample; the fp32
+                         # oracle itself sits 1.4e-6 from an f64 evaluation of yolov8n
+EXACT_BOX_EPS = 5e-3     # letterboxed px on coordinates up to 640 (f32 ulp there: 6e-5)
+
+
+def _assert_keepset_equals_golden(det_out, j, gold, prefix, conf_key, scale_px=1.0):
+    boxes, scores, cls, src, counts = det_out
+    g_src = gold[f"{prefix}src"]
+    k = int(counts[j])
+    assert k == len(g_src), f"{prefix}: {k} detections, fp32 golden has {len(g_src)}"
+    assert np.array_equal(src[j, :k], g_src), f"{prefix}: keep-set (anchor indices, in order) differs from the fp32 golden"
+    if f"{prefix}cls" in gold.files:
+        assert np.array_equal(cls[j, :k], gold[f"{prefix}cls"]), f"{prefix}: classes differ"
+    ds = float(np.abs(scores[j, :k] - gold[f"{prefix}scores"]).max()) if k else 0.0
+    db = float(np.abs(boxes[j, :k] - gold[f"{prefix}boxes"]).max()) if k else 0.0
+    assert ds <= EXACT_SCORE_EPS and db <= EXACT_BOX_EPS * scale_px, f"{prefix}: scores off by {ds}, boxes by {db} px"
+    return k, ds, db
+
+
+@pytest.mark.parametrize("scale,frames", [("n", [(3, 40), (2, 50), (4, 0)]), ("l", [(3, 40), (2, 50)])])
+def test_yolo_exact_plan_keepsets_equal_fp32(cuda, scale, frames):
+    """precision="exact" from raw 1080p frames: detect() returns EXACTLY the fp32 oracle's keep-set (anchor indices in NMS
+    order), classes and count at conf 0.25 and 0.5 for every golden frame; scores within 1e-5, frame-pixel boxes within
+    1.5e-2 px (gain 1/3).  The raw prediction tensor is compared with the committed sample of the oracle's."""
+    from lmx import synth, yolo
+
+    cfg = yolo.YoloConfig(scale)
+    sd = yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path(scale))
+    det = yolo.YoloDetector(cfg, sd, cuda)  # default plan = exact
+    assert det.precision == "exact"
+    gold = np.load(os.path.join(GOLD, f"yolov8{scale}_det_w7.npz"))
+    fr = np.stack([synth.synth_frame(cs, fi) for cs, fi in frames], 0)
+    d_fr = torch.from_numpy(fr).to(cuda)
+    img, geo = det.preprocess(d_fr)
+    pred = det.forward_letterboxed(img).cpu().numpy()
+    report = []
+    for j in range(len(frames)):
+        ref = gold[f"f{j}_pred_sample"]  # rows [::97] of the fp32 oracle's [A, 84]
+        got = pred[j][::97]
+        eps_s, eps_b = float(np.abs(got[:, 4:] - ref[:, 4:]).max()), float(np.abs(got[:, :4] - ref[:, :4]).max())
+        assert eps_s <= EXACT_SCORE_EPS and eps_b <= EXACT_BOX_EPS, f"frame {j}: prediction off by {eps_s} (scores) / {eps_b} px"
+        report.append(("pred", j, eps_s, eps_b))
+    for conf in (0.25, 0.5):
+        out = tuple(t.cpu().numpy() for t in det.detect(d_fr, conf=conf))
+        for j in range(len(frames)):
+            report.append((j, conf) + _assert_keepset_equals_golden(out, j, gold, f"f{j}_c{int(conf * 100)}_", conf, 3.0))
+    print(f"yolov8{scale} exact plan (frame, conf, kept = fp32 kept, max score diff, max box diff px):", report)
+    # the plan is batch-independent and reproducible like the f16 one
+    alone = det.forward_letterboxed(img[1:2]).cpu().numpy()
+    assert np.array_equal(alone[0], pred[1]), "exact plan: frame alone differs from the frame inside the batch"
+
+
+def test_cfg2_exact_plan_golden_frames(cuda):
+    """BASELINE cfg#2's two golden frames (640 x 640, indices 0 and 31 of the batch) on the exact plan: keep-sets identical
+    to the fp32 goldens at conf 0.25 and 0.5, and eps measured against the oracle's full prediction (all 8400 anchors)."""
+    from lmx import synth, yolo
+
+    g = np.load(os.path.join(GOLD, "yolov8l_cfg2_w7.npz"))
+    cfg = yolo.YoloConfig("l")
+    det = yolo.YoloDetector(cfg, yolo.synthetic_state_dict(cfg, int(g["weight_seed"]), yolo.bn_stats_path("l")), cuda)
+    fr = synth.cfg2_frames()[[int(i) for i in g["frame_ids"]]]
+    d_fr = torch.from_numpy(fr).to(cuda)
+    img, _ = det.preprocess(d_fr)
+    pred = det.forward_letterboxed(img).cpu().numpy()
+    report = []
+    for j in range(2):
+        score = pred[j][:, 4:].max(1)
+        eps_s = float(np.abs(score - g[f"f{j}_score"]).max())
+        eps_b = float(np.abs(pred[j][:, :4] - g[f"f{j}_box"]).max())
+        assert np.array_equal(pred[j][:, 4:].argmax(1), g[f"f{j}_cls"]) or eps_s <= EXACT_SCORE_EPS
+        assert eps_s <= EXACT_SCORE_EPS and eps_b <= EXACT_BOX_EPS, f"cfg2 frame {j}: eps_score {eps_s} eps_box {eps_b}"
+        report.append(("pred", j, eps_s, eps_b))
+    for conf in (0.25, 0.5):
+        out = tuple(t.cpu().numpy() for t in det.detect(d_fr, conf=conf))
+        for j in range(2):
+            report.append((j, conf) + _assert_keepset_equals_golden(out, j, g, f"f{j}_c{int(conf * 100)}_", conf))
+    print("cfg2 exact plan (frame, conf, kept = fp32 kept, max score diff, max box diff px):", report)
+
+
+def test_pose_exact_plan_equals_fp32(cuda):
+    """YOLOv8n-pose on the exact plan: the kept detections ARE the fp32 oracle's (anchor indices in order), keypoints within
+    2e-2 frame px and 1e-5 in visibility."""
+    from lmx import synth, yolo
+
+    kshape = (17, 3)
+    cfg = yolo.YoloConfig("n", nc=1, kpt_shape=kshape)
+    det = yolo.YoloDetector(cfg, yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path("n", pose=True)), cuda)
+    gold = np.load(os.path.join(GOLD, "yolov8n-pose_det_w7.npz"))
+    conf = float(gold["conf"])
+    fr = np.stack([synth.synth_frame(int(cs), int(fi)) for cs, fi in gold["frames"]], 0)
+    boxes, scores, cls, src, counts, kpts = (t.cpu().numpy() for t in det.detect_pose(torch.from_numpy(fr).to(cuda), conf=conf))
+    for j in range(fr.shape[0]):
+        k, ds, db = _assert_keepset_equals_golden((boxes, scores, cls, src, counts), j, gold, f"f{j}_", conf, 3.0)
+        dk = float(np.abs(kpts[j, :k, :, :2] - gold[f"f{j}_keypoints"][..., :2]).max())
+        dv = float(np.abs(kpts[j, :k, :, 2] - gold[f"f{j}_keypoints"][..., 2]).max())
+        print(f"pose exact frame {j}: {k} detections = fp32, scores {ds:.1e}, boxes {db:.1e} px, keypoints {dk:.1e} px, visibility {dv:.1e}")
+        assert dk <= 2e-2 and dv <= EXACT_SCORE_EPS

@@ -59,7 +59,7 @@ def test_scale_boxes_known_answer():
 
 def test_fold_and_names_agree_with_oracle():
     cfg = yolo.YoloConfig("n")
-    sd = yolo.synthetic_state_dict(cfg, 7, os.path.join(GOLD, "yolov8n_bn_w7.npz"))
+    sd = yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path("n"))
     # every name the oracle touches exists, and the oracle's own fold equals lmx's
     x = torch.rand(1, 3, 64, 64)
     seen = []
@@ -89,7 +89,7 @@ def test_fold_and_names_agree_with_oracle():
 def test_oracle_detections_match_committed_golden():
     g = np.load(os.path.join(GOLD, "yolov8n_det_w7.npz"))
     cfg = yolo.YoloConfig("n")
-    sd = yolo.synthetic_state_dict(cfg, int(g["weight_seed"]), os.path.join(GOLD, "yolov8n_bn_w7.npz"))
+    sd = yolo.synthetic_state_dict(cfg, int(g["weight_seed"]), yolo.bn_stats_path("n"))
     cs, fi = g["frames"][2]
     r = OY.predict("n", 80, sd, synth.synth_frame(int(cs), int(fi)), conf=0.5)
     assert np.array_equal(r["src"], g["f2_c50_src"]) and np.array_equal(r["cls"], g["f2_c50_cls"])
@@ -131,7 +131,7 @@ def test_pose_decode_and_scale_coords_known_answers():
 
 def test_pose_oracle_matches_committed_golden():
     cfg = yolo.YoloConfig("n", nc=1, kpt_shape=(17, 3))
-    sd = yolo.synthetic_state_dict(cfg, 7, os.path.join(GOLD, "yolov8n-pose_bn_w7.npz"))
+    sd = yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path("n", pose=True))
     gold = np.load(os.path.join(GOLD, "yolov8n-pose_det_w7.npz"))
     cs, fi = gold["frames"][0]
     r = OY.predict_pose("n", 1, (17, 3), sd, synth.synth_frame(int(cs), int(fi)), conf=float(gold["conf"]))

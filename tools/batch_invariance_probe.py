@@ -44,7 +44,7 @@ for (h, w_, cin, cout) in [(12, 20, 256, 256), (24, 40, 128, 128), (48, 80, 64, 
     print(f"conv3x3 {h}x{w_} cin={cin} cout={cout}: {'identical' if torch.equal(o1, o3) else 'DIFFERENT max ' + str(float((o1.float() - o3.float()).abs().max()))}")
 for scale in ("n", "l"):
     cfg = yolo.YoloConfig(scale)
-    det = yolo.YoloDetector(cfg, yolo.synthetic_state_dict(cfg, 7, os.path.join(ROOT, "tests", "golden", f"yolov8{scale}_bn_w7.npz")), dev)
+    det = yolo.YoloDetector(cfg, yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path(scale)), dev)
     fr = torch.from_numpy(np.stack([synth.synth_frame(3, 40 + 3 * i) for i in range(3)], 0)).to(dev)
     img, _ = det.preprocess(fr)
     p3 = det.forward_letterboxed(img)

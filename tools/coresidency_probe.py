@@ -71,7 +71,7 @@ def foreground():
         return (m != ref).sum()
     if fgk == "maskp":
         K.check(K._lib.load().lmx_k_mask_post(K._ptr(logits), 16, 256, 1024, 576, 1024, 1080, 1920, K._ptr(p_mask), K._ptr(p_stats),
-                                              K._ptr(p_ws), K._stream()), "mask_post")
+                                              K._ptr(p_ws), K._stream(logits.device)), "mask_post")
         return (p_mask != ref).sum()
     K.layernorm(xf, gam, bet, 1e-6, out=ln_out)
     return (ln_out != ln_ref).sum()

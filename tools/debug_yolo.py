@@ -13,7 +13,7 @@ import oracle.yolo as OY  # noqa: E402
 
 scale = sys.argv[1] if len(sys.argv) > 1 else "n"
 cfg = yolo.YoloConfig(scale)
-sd = yolo.synthetic_state_dict(cfg, 7, os.path.join(ROOT, "tests", "golden", f"yolov8{scale}_bn_w7.npz"))
+sd = yolo.synthetic_state_dict(cfg, 7, yolo.bn_stats_path(scale))
 dev = torch.device("cuda:0")
 det = yolo.YoloDetector(cfg, sd, dev)
 f = synth.synth_frame(3, 40)

@@ -30,7 +30,7 @@ for nm, cfg in (("sam_vit_b", sam.sam_vit_b()), ("sam_vit_h", sam.sam_vit_h())):
     del enc
     torch.cuda.empty_cache()
 cfg = yolo.YoloConfig("n", nc=1, kpt_shape=(17, 3))
-gold = os.path.join(ROOT, "tests", "golden", "yolov8n-pose_bn_w7.npz")
+gold = yolo.bn_stats_path("n", pose=True)
 det = yolo.YoloDetector(cfg, yolo.synthetic_state_dict(cfg, 7, gold), dev)
 rep("yolov8n-pose", lambda: det.detect_pose(frames, conf=0.05))
 dcfg = dino.dinov2_base()

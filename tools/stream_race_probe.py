@@ -46,7 +46,7 @@ def mask_post_keep(logits, T, nh_, nw_, h_, w_):
     mask = torch.empty((n, h_, w_), dtype=torch.uint8, device=logits.device)
     stats = torch.empty((n, 8), dtype=torch.int64, device=logits.device)
     ws = torch.empty((n, nh_, nw_), dtype=torch.float32, device=logits.device)
-    K.check(_lib.load().lmx_k_mask_post(_ptr(logits), n, L, T, nh_, nw_, h_, w_, _ptr(mask), _ptr(stats), _ptr(ws), _stream()), "mask_post")
+    K.check(_lib.load().lmx_k_mask_post(_ptr(logits), n, L, T, nh_, nw_, h_, w_, _ptr(mask), _ptr(stats), _ptr(ws), _stream(logits.device)), "mask_post")
     kept.append(ws)
     return mask, stats
 

@@ -15,7 +15,7 @@ from lmx import yolo, synth
 from oracle import yolo as OY
 import keepset as KS
 scale='n'
-cfg=yolo.YoloConfig(scale); sd=yolo.synthetic_state_dict(cfg,7,f'/root/repo/tests/golden/yolov8{scale}_bn_w7.npz')
+cfg=yolo.YoloConfig(scale); sd=yolo.synthetic_state_dict(cfg,7,yolo.bn_stats_path(scale))
 fr=synth.synth_frame(3,40)
 ref=OY.predict(scale,80,sd,fr,conf=0.25)
 cref=KS.compact_pred(ref['pred'])

@@ -295,7 +295,7 @@ extern "C" int lmx_k_gemm(const lmx_gemm_desc* dp, lmx_stream_t stream) {
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // large dense problems take the LDS-DMA 256x128 kernel (gemm2.hip); small / narrow ones and the conv generator stay here
-  const bool conv_ok = d.a_mode == 1 && d.Cin % 32 == 0 && d.out_dtype == LMX_F16 && d.H < 32768 && d.W_ < 32768;
+  const bool conv_ok = d.a_mode == 1 && d.Cin % 32 == 0 && d.H < 32768 && d.W_ < 32768;  // (f32 out: the exact plan's pre-activations)
   if (d.a_mode == 2) return lmx_gemm2_launch(d, st);
   if ((d.a_mode == 0 || conv_ok) && d.M >= 512 && d.N >= 96 && d.N % 8 == 0 && d.ldc % 8 == 0 && (!d.res || d.ldr % 8 == 0) &&
       aligned16(d.C) && (!d.res || aligned16(d.res)) && !force_v1())

@@ -62,6 +62,9 @@ SIGNATURES = {
     "lmx_k_nms": (_I, [_VP, _I, _I, _I, _F, _D, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "lmx_k_letterbox": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _VP]),
     "lmx_k_stem_conv": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "lmx_k_split3": (_I, [_VP, _I64, _I, _VP, _I64, _VP, _I64, _I64, _I, _I, _VP]),
+    "lmx_k_maxpool5_x3": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
+    "lmx_k_stem_conv_x3": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "lmx_k_maxpool5": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
     "lmx_k_upsample2": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
     "lmx_k_detect_decode": (_I, [_VP, _I64, _VP, _I, _I, _I, _I, _F, _I, _I, _VP]),

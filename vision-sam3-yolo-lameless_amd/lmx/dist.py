@@ -65,12 +65,13 @@ def unpack_records(buf, layout, keep_valid_only=True):
     return out
 
 
-def check_equal_rows(n_rows):
+def check_equal_rows(n_rows, device=None):
     """Every rank must contribute the same number of rows, or the collective hangs (RCCL) / errors (gloo): one cheap
-    all-reduce of (min, -max) catches a caller that forgot to pad."""
+    all-reduce of (min, -max) catches a caller that forgot to pad.  `device`: where the records live (RCCL reduces in HBM of
+    THAT device, not of the process's current one)."""
     t = torch.tensor([n_rows, -n_rows], dtype=torch.int64)
     if dist.get_backend() != "gloo":
-        t = t.cuda()
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     lo, hi = int(t[0]), -int(t[1])
     if lo != hi:
@@ -82,7 +83,7 @@ def gather_packed(buf, root=None, check=False):
     when root is None (all-gather).  gloo moves host tensors (CPU tests, single-GPU rehearsals); nccl = RCCL moves HBM."""
     world = dist.get_world_size()
     if check:
-        check_equal_rows(int(buf.shape[0]))
+        check_equal_rows(int(buf.shape[0]), buf.device)
     dev = buf.device
     via_host = dist.get_backend() == "gloo" and dev.type != "cpu"
     src = buf.contiguous().cpu() if via_host else buf.contiguous()

@@ -2,6 +2,7 @@
 every function below checks shapes/strides on the host, fills the C descriptor and enqueues ONE liblmx kernel on
 torch's current HIP stream.  No arithmetic happens in Python and there is no fallback path."""
 import ctypes as C
+import threading
 
 import torch
 
@@ -13,12 +14,14 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
 _DT = {torch.float16: F16, torch.float32: F32}
 
 
-_cur_dev = None  # device of the operands of the wrapper that is being executed (set by _dev, read by _stream)
+_tls = threading.local()  # .dev: device of the launch being issued by THIS thread (read by the launch trace only)
 
 
-def _stream():
-    """The HIP stream the launch goes to: torch's current stream OF THE OPERANDS' DEVICE (not of the current device)."""
-    return C.c_void_p(torch.cuda.current_stream(_cur_dev).cuda_stream)
+def _stream(dev):
+    """The HIP stream the launch goes to: torch's current stream OF THE OPERANDS' DEVICE `dev` (what _dev returned), not of
+    the current device.  The device is passed explicitly: two threads driving two devices do not share any state here."""
+    _tls.dev = dev
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _ptr(t):
@@ -26,8 +29,7 @@ def _ptr(t):
 
 
 def _dev(*ts):
-    """Every operand must live in HBM, all on one device; remembers that device for _stream()."""
-    global _cur_dev
+    """Every operand must live in HBM, all on one device; returns that device (the argument of _stream)."""
     dev = None
     for t in ts:
         if t is None:
@@ -38,8 +40,9 @@ def _dev(*ts):
             dev = t.device
         elif t.device != dev:
             raise LmxError(f"lmx kernels: operands on different devices ({dev} and {t.device})")
-    if dev is not None:
-        _cur_dev = dev
+    if dev is None:
+        raise LmxError("lmx kernels: no device operand")
+    return dev
 
 
 def _rows(t, what):
@@ -61,7 +64,7 @@ def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtyp
     pool_hw=(H, W): the rows of `a` are an [n, H, W] token grid and the result is the 2 x 2 max-pool of the product over that
     grid, [M/4, N] in [n, H/2, W/2] order (a_mode 2: the bits of gemm(...) followed by maxpool2, without the full-size
     intermediate)."""
-    _dev(a, w, bias, scale, res, out)
+    dev = _dev(a, w, bias, scale, res, out)
     M, K, lda = _rows(a, "gemm A")
     N, K2, ldw = _rows(w, "gemm W")
     if K2 != K or ldw != K:
@@ -93,39 +96,40 @@ def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtyp
     d.act, d.out_dtype, d.a_mode = act, _DT[out.dtype], 0
     if pool_hw:
         d.a_mode, d.H, d.W_ = 2, int(pool_hw[0]), int(pool_hw[1])
-    check(_lib.load().lmx_k_gemm(C.byref(d), _stream()), "lmx_k_gemm")
+    check(_lib.load().lmx_k_gemm(C.byref(d), _stream(dev)), "lmx_k_gemm")
     return out
 
 
 def im2col_u8(img, lut, IH, IW, KH, KW, stride, pad, ldo):
     """u8 [n,rh,rw,3] at the top-left of an IH x IW zero canvas -> f16 [n*OH*OW, ldo] (lmx_k_im2col_u8)."""
-    _dev(img, lut)
+    dev = _dev(img, lut)
     n, rh, rw, c = img.shape
     if c != 3 or img.dtype != torch.uint8 or not img.is_contiguous():
         raise LmxError("im2col_u8: img must be contiguous uint8 [n,h,w,3]")
     OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
     out = torch.empty((n * OH * OW, ldo), dtype=torch.float16, device=img.device)
     check(_lib.load().lmx_k_im2col_u8(_ptr(img), _ptr(lut), _ptr(out), n, rh, rw, IH, IW, KH, KW, stride, pad, ldo,
-                                      _stream()), "lmx_k_im2col_u8")
+                                      _stream(dev)), "lmx_k_im2col_u8")
     return out
 
 
 def maxpool2(x, out):
     """2x2/s2 max pool, NHWC f16 or f32, channel slices allowed (lmx_k_maxpool2)."""
+    dev = _dev(x, out)
     n, H, W, Cc, ps = _nhwc(x, "maxpool2 x")
     no, Ho, Wo, Co, pso = _nhwc(out, "maxpool2 out")
     if (no, Ho, Wo, Co) != (n, H // 2, W // 2, Cc) or x.dtype != out.dtype:
         raise LmxError("maxpool2: shape/dtype mismatch")
-    check(_lib.load().lmx_k_maxpool2(_ptr(x), ps, _ptr(out), pso, _DT[x.dtype], n, H, W, Cc, _stream()), "lmx_k_maxpool2")
+    check(_lib.load().lmx_k_maxpool2(_ptr(x), ps, _ptr(out), pso, _DT[x.dtype], n, H, W, Cc, _stream(dev)), "lmx_k_maxpool2")
     return out
 
 
 def cast_f16(x, out=None):
-    _dev(x, out)
+    dev = _dev(x, out)
     rows, cols, lds = _rows(x, "cast src")
     if out is None:
         out = torch.empty((rows, cols), dtype=torch.float16, device=x.device)
-    check(_lib.load().lmx_k_cast_f32_f16(_ptr(x), lds, _ptr(out), out.stride(0), rows, cols, _stream()),
+    check(_lib.load().lmx_k_cast_f32_f16(_ptr(x), lds, _ptr(out), out.stride(0), rows, cols, _stream(dev)),
           "lmx_k_cast_f32_f16")
     return out
 
@@ -141,24 +145,27 @@ def _nhwc(t, what):
     return n, H, W, Cc, ps
 
 
-def conv3x3(x, w, bias=None, act=ACT_SILU, stride=1, res=None, out=None):
+def conv3x3(x, w, bias=None, act=ACT_SILU, stride=1, res=None, out=None, scale=None, out_dtype=torch.float16):
     """3x3 / pad 1 convolution as implicit GEMM (lmx_k_gemm, a_mode 1).  x: NHWC f16 (may be a channel slice),
-    w: f16 [Cout, 9*Cin] packed (ky,kx,ci); out: NHWC f16 (may be a channel slice of a wider buffer)."""
-    _dev(x, w, bias, res, out)
+    w: f16 [Cout, 9*Cin] packed (ky,kx,ci); out: NHWC f16 or f32 (may be a channel slice of a wider buffer);
+    scale: f32 [Cout] applied after bias + activation (the exact plan's power-of-two row scales)."""
+    dev = _dev(x, w, bias, res, out, scale)
     n, H, W, Cin, ps = _nhwc(x, "conv3x3 x")
     Cout = w.shape[0]
     if w.dim() != 2 or w.shape[1] != 9 * Cin or not w.is_contiguous():
         raise LmxError(f"conv3x3: W must be contiguous [Cout, 9*Cin={9 * Cin}], got {tuple(w.shape)}")
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
     if out is None:
-        out = torch.empty((n, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
+        out = torch.empty((n, Ho, Wo, Cout), dtype=out_dtype, device=x.device)
     no, Ho2, Wo2, Co2, pso = _nhwc(out, "conv3x3 out")
     if (no, Ho2, Wo2, Co2) != (n, Ho, Wo, Cout):
         raise LmxError(f"conv3x3: out shape {tuple(out.shape)} != {(n, Ho, Wo, Cout)}")
     d = GemmDesc()
     d.A, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
-    d.scale = None
+    if scale is not None and (scale.dtype != torch.float32 or scale.numel() != Cout):
+        raise LmxError("conv3x3: scale must be float32 [Cout]")
+    d.scale = scale.data_ptr() if scale is not None else None
     d.lda, d.ldc, d.ldr = ps, pso, 0
     if res is not None:
         nr, Hr, Wr, Cr, psr = _nhwc(res, "conv3x3 res")
@@ -166,13 +173,13 @@ def conv3x3(x, w, bias=None, act=ACT_SILU, stride=1, res=None, out=None):
             raise LmxError("conv3x3: residual must match out")
         d.res, d.ldr = res.data_ptr(), psr
     d.M, d.N, d.K = n * Ho * Wo, Cout, 9 * Cin
-    d.act, d.out_dtype, d.a_mode = act, F16, 1
+    d.act, d.out_dtype, d.a_mode = act, _DT[out.dtype], 1
     d.H, d.W_, d.Cin, d.conv_stride, d.Ho, d.Wo = H, W, Cin, stride, Ho, Wo
-    check(_lib.load().lmx_k_gemm(C.byref(d), _stream()), "lmx_k_gemm(conv3x3)")
+    check(_lib.load().lmx_k_gemm(C.byref(d), _stream(dev)), "lmx_k_gemm(conv3x3)")
     return out
 
 
-def conv1x1(x, w, bias=None, act=ACT_SILU, res=None, out=None, out_dtype=torch.float16):
+def conv1x1(x, w, bias=None, act=ACT_SILU, res=None, out=None, out_dtype=torch.float16, scale=None):
     """1x1 convolution = GEMM over the pixels of an NHWC tensor (channel slices allowed on both sides)."""
     n, H, W, Cin, ps = _nhwc(x, "conv1x1 x")
     a = x.as_strided((n * H * W, Cin), (ps, 1))
@@ -185,12 +192,12 @@ def conv1x1(x, w, bias=None, act=ACT_SILU, res=None, out=None, out_dtype=torch.f
     if res is not None:
         nr, Hr, Wr, Cr, psr = _nhwc(res, "conv1x1 res")
         r2 = res.as_strided((n * H * W, Cout), (psr, 1))
-    gemm(a, w, bias=bias, act=act, res=r2, out=o2)
+    gemm(a, w, bias=bias, act=act, res=r2, out=o2, scale=scale)
     return out
 
 
 def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16, act=ACT_NONE):
-    _dev(x, gamma, beta, out)
+    dev = _dev(x, gamma, beta, out)
     rows, D, ldx = _rows(x, "layernorm x")
     if out is None:
         out = torch.empty((rows, D), dtype=out_dtype, device=x.device)
@@ -198,19 +205,19 @@ def layernorm(x, gamma, beta, eps, out=None, out_dtype=torch.float16, act=ACT_NO
     if (r2, D2) != (rows, D):
         raise LmxError("layernorm: out shape mismatch")
     check(_lib.load().lmx_k_layernorm(_ptr(x), _DT[x.dtype], ldx, _ptr(gamma), _ptr(beta), _ptr(out), _DT[out.dtype],
-                                      ldy, rows, D, float(eps), act, _stream()), "lmx_k_layernorm")
+                                      ldy, rows, D, float(eps), act, _stream(dev)), "lmx_k_layernorm")
     return out
 
 
 def pack_bits(mask):
     """u8 [..., h, w] (0 / non-0) -> u8 [..., h, ceil(w/8)], numpy.packbits bit order."""
-    _dev(mask)
+    dev = _dev(mask)
     if mask.dtype not in (torch.uint8, torch.bool) or not mask.is_contiguous():
         raise LmxError("pack_bits: contiguous uint8 / bool tensor expected")
     w = mask.shape[-1]
     rows = mask.numel() // w
     out = torch.empty(tuple(mask.shape[:-1]) + ((w + 7) // 8,), dtype=torch.uint8, device=mask.device)
-    check(_lib.load().lmx_k_pack_bits(_ptr(mask), rows, w, _ptr(out), _stream()), "lmx_k_pack_bits")
+    check(_lib.load().lmx_k_pack_bits(_ptr(mask), rows, w, _ptr(out), _stream(dev)), "lmx_k_pack_bits")
     return out
 
 
@@ -222,7 +229,7 @@ def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps, x16=None, next_ln=None):
     x16: optional f16 [rows, D] that also receives the updated x (saves a cast pass where an f16 copy is needed next).
     next_ln=(gamma, beta, h): h (f16 [rows, D]) receives LayerNorm(updated x; gamma, beta, eps) — the next block's first
     LayerNorm, without its launch."""
-    _dev(x, gamma, beta, w1, b1, w2, b2, x16, *(next_ln or ()))
+    dev = _dev(x, gamma, beta, w1, b1, w2, b2, x16, *(next_ln or ()))
     rows, D, ldx = _rows(x, "ln_mlp x")
     if x.dtype != torch.float32 or w1.dtype != torch.float16 or w2.dtype != torch.float16:
         raise LmxError("ln_mlp: x must be f32 and the weights f16")
@@ -235,7 +242,7 @@ def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps, x16=None, next_ln=None):
         raise LmxError("ln_mlp: next_ln = (gamma [D], beta [D], contiguous float16 [rows, D])")
     ws = torch.empty((rows, D), dtype=torch.float16, device=x.device)  # LayerNorm output (the library's workspace)
     check(_lib.load().lmx_k_ln_mlp(_ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), rows, D,
-                                   float(eps), _ptr(ws), _ptr(x16), _ptr(gn), _ptr(bn), _ptr(hn), _stream()), "lmx_k_ln_mlp")
+                                   float(eps), _ptr(ws), _ptr(x16), _ptr(gn), _ptr(bn), _ptr(hn), _stream(dev)), "lmx_k_ln_mlp")
     return x
 
 
@@ -262,25 +269,25 @@ def attention(q, k, v, out, B, H, Tq, Tk, hd, scale, window=None, pad_k=None, pa
     """q/k/v/out: 2-D token-row views [rows, >=H*hd] (row stride = ld).  window = None (flat: row = b*T + t) or
     dict(Gh, Gw, ws, q_stride) for in-place window addressing on the token grid.
     rel_pos = (rel_pos_h, rel_pos_w) f32 [2S-1, hd] adds SAM v1's decomposed relative-position bias (S*S == Tk)."""
-    _dev(q, k, v, out, pad_k, pad_v)
+    dev = _dev(q, k, v, out, pad_k, pad_v)
     d = _attn_desc(q, k, v, out, B, H, Tq, Tk, hd, scale, window, pad_k, pad_v)
     keep = None
     if rel_pos is not None:
         rh, rw = rel_pos
-        _dev(rh, rw)
+        _dev(rh, rw, q)
         S = (rh.shape[0] + 1) // 2
         if S * S != Tk or Tq != Tk or rh.dtype != torch.float32 or tuple(rh.shape) != (2 * S - 1, hd) or rh.shape != rw.shape:
             raise LmxError("attention: rel_pos tables must be float32 [2S-1, hd] with S*S == Tq == Tk")
         keep = torch.empty((B * H * Tq, 2 * S), dtype=torch.float16, device=q.device)
-        check(_lib.load().lmx_k_relpos_tables(C.byref(d), _ptr(rh), _ptr(rw), S, _ptr(keep), _stream()), "lmx_k_relpos_tables")
+        check(_lib.load().lmx_k_relpos_tables(C.byref(d), _ptr(rh), _ptr(rw), S, _ptr(keep), _stream(dev)), "lmx_k_relpos_tables")
         d.rel, d.rel_S = keep.data_ptr(), S
-    check(_lib.load().lmx_k_attention(C.byref(d), _stream()), "lmx_k_attention")
+    check(_lib.load().lmx_k_attention(C.byref(d), _stream(dev)), "lmx_k_attention")
     return out
 
 
 def rope(x, B, T, H, hd, n_prefix, cos_t, sin_t):
-    _dev(x, cos_t, sin_t)
-    check(_lib.load().lmx_k_rope(_ptr(x), x.stride(0), B, T, H, hd, n_prefix, _ptr(cos_t), _ptr(sin_t), _stream()),
+    dev = _dev(x, cos_t, sin_t)
+    check(_lib.load().lmx_k_rope(_ptr(x), x.stride(0), B, T, H, hd, n_prefix, _ptr(cos_t), _ptr(sin_t), _stream(dev)),
           "lmx_k_rope")
     return x
 
@@ -288,7 +295,7 @@ def rope(x, B, T, H, hd, n_prefix, cos_t, sin_t):
 def pil_resize(src, dw, dh, tab_h, tab_v, swap_rb=False):
     """Pillow-exact two-pass resize of u8 [n,sh,sw,3] -> [n,dh,dw,3].  tab_* = (bounds i32 [2*out], kk i32
     [out*ksize], ksize) device tensors from lmx.resample.coeff_tables; None skips that pass (size unchanged)."""
-    _dev(src)
+    dev = _dev(src)
     n, sh, sw, c = src.shape
     if c != 3 or src.dtype != torch.uint8 or not src.is_contiguous():
         raise LmxError("pil_resize: src must be contiguous uint8 [n,h,w,3]")
@@ -298,7 +305,7 @@ def pil_resize(src, dw, dh, tab_h, tab_v, swap_rb=False):
         bounds, kk, ksize = tab_h
         tmp = torch.empty((n, sh, dw, 3), dtype=torch.uint8, device=src.device)
         check(lib.lmx_k_pil_resize_h(_ptr(cur), _ptr(tmp), n, sh, sw, dw, _ptr(bounds), _ptr(kk), ksize,
-                                     1 if swap_rb else 0, _stream()), "lmx_k_pil_resize_h")
+                                     1 if swap_rb else 0, _stream(dev)), "lmx_k_pil_resize_h")
         cur = tmp
     elif swap_rb:
         raise LmxError("pil_resize: swap_rb needs the horizontal pass")
@@ -307,14 +314,14 @@ def pil_resize(src, dw, dh, tab_h, tab_v, swap_rb=False):
         w = cur.shape[2]
         dst = torch.empty((n, dh, w, 3), dtype=torch.uint8, device=src.device)
         check(lib.lmx_k_pil_resize_v(_ptr(cur), _ptr(dst), n, cur.shape[1], dh, w, _ptr(bounds), _ptr(kk), ksize,
-                                     _stream()), "lmx_k_pil_resize_v")
+                                     _stream(dev)), "lmx_k_pil_resize_v")
         cur = dst
     return cur
 
 
 def patchify_norm(img, top, left, gh, gw, P, lut, k_pad=None):
     """-> f16 [n*gh*gw, k_pad or P*P*3] patch matrix (columns beyond P*P*3 zero)."""
-    _dev(img, lut)
+    dev = _dev(img, lut)
     n, ih, iw, c = img.shape
     if c != 3 or img.dtype != torch.uint8 or not img.is_contiguous():
         raise LmxError("patchify_norm: img must be contiguous uint8 [n,h,w,3]")
@@ -323,28 +330,28 @@ def patchify_norm(img, top, left, gh, gw, P, lut, k_pad=None):
     alloc = torch.zeros if ldo != K else torch.empty
     out = alloc((n * gh * gw, ldo), dtype=torch.float16, device=img.device)
     check(_lib.load().lmx_k_patchify_norm(_ptr(img), _ptr(out), n, ih, iw, top, left, gh, gw, P, ldo, _ptr(lut),
-                                          _stream()), "lmx_k_patchify_norm")
+                                          _stream(dev)), "lmx_k_patchify_norm")
     return out
 
 
 def assemble_tokens(patch, prefix, pos, B, np_, n_prefix, D):
-    _dev(patch, prefix, pos)
+    dev = _dev(patch, prefix, pos)
     out = torch.empty((B * (np_ + n_prefix), D), dtype=torch.float32, device=patch.device)
     check(_lib.load().lmx_k_assemble_tokens(_ptr(patch), _ptr(prefix), _ptr(pos), _ptr(out), B, np_, n_prefix, D,
-                                            _stream()), "lmx_k_assemble_tokens")
+                                            _stream(dev)), "lmx_k_assemble_tokens")
     return out
 
 
 def token_mean(x, B, T, D):
-    _dev(x)
+    dev = _dev(x)
     out = torch.empty((B, D), dtype=torch.float32, device=x.device)
-    check(_lib.load().lmx_k_token_mean(_ptr(x), _DT[x.dtype], _ptr(out), B, T, D, _stream()), "lmx_k_token_mean")
+    check(_lib.load().lmx_k_token_mean(_ptr(x), _DT[x.dtype], _ptr(out), B, T, D, _stream(dev)), "lmx_k_token_mean")
     return out
 
 
 def nms(pred, conf, iou=0.7, max_det=300, max_wh=7680.0):
     """pred f32 [n,A,4+nc] -> (boxes [n,max_det,4], scores, cls, src, counts) on device (lmx_k_nms)."""
-    _dev(pred)
+    dev = _dev(pred)
     if pred.dtype != torch.float32 or pred.dim() != 3 or not pred.is_contiguous():
         raise LmxError("nms: pred must be contiguous float32 [n,A,4+nc]")
     n, A, row = pred.shape
@@ -356,27 +363,27 @@ def nms(pred, conf, iou=0.7, max_det=300, max_wh=7680.0):
     src = torch.full((n, max_det), -1, dtype=torch.int32, device=pred.device)
     counts = torch.zeros((n,), dtype=torch.int32, device=pred.device)
     check(lib.lmx_k_nms(_ptr(pred), n, A, row - 4, float(conf), float(iou), max_det, float(max_wh), _ptr(boxes),
-                        _ptr(scores), _ptr(cls), _ptr(src), _ptr(counts), _ptr(ws), _stream()), "lmx_k_nms")
+                        _ptr(scores), _ptr(cls), _ptr(src), _ptr(counts), _ptr(ws), _stream(dev)), "lmx_k_nms")
     return boxes, scores, cls, src, counts
 
 
 # ---- YOLO pieces ------------------------------------------------------------------------------------------
 def letterbox(frames, geo, tables, swap_rb=True):
     """u8 [n,sh,sw,3] -> u8 [n,oh,ow,3]; geo from lmx.letterbox.geometry, tables = device (xofs, ialpha, yofs, ibeta)."""
-    _dev(frames)
+    dev = _dev(frames)
     n, sh, sw, c = frames.shape
     if c != 3 or frames.dtype != torch.uint8 or not frames.is_contiguous():
         raise LmxError("letterbox: frames must be contiguous uint8 [n,h,w,3]")
     out = torch.empty((n, geo.oh, geo.ow, 3), dtype=torch.uint8, device=frames.device)
     xo, ia, yo, ib = tables if tables is not None else (None, None, None, None)
     check(_lib.load().lmx_k_letterbox(_ptr(frames), _ptr(out), n, sh, sw, geo.rh, geo.rw, geo.top, geo.left, geo.oh, geo.ow,
-                                      _ptr(xo), _ptr(ia), _ptr(yo), _ptr(ib), 1 if swap_rb else 0, _stream()),
+                                      _ptr(xo), _ptr(ia), _ptr(yo), _ptr(ib), 1 if swap_rb else 0, _stream(dev)),
           "lmx_k_letterbox")
     return out
 
 
 def stem_conv(img_u8, w, bias, out=None):
-    _dev(img_u8, w, bias, out)
+    dev = _dev(img_u8, w, bias, out)
     n, H, W, _ = img_u8.shape
     Cout = bias.numel()
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -384,54 +391,95 @@ def stem_conv(img_u8, w, bias, out=None):
         out = torch.empty((n, Ho, Wo, Cout), dtype=torch.float16, device=img_u8.device)
     if not out.is_contiguous() or tuple(out.shape) != (n, Ho, Wo, Cout):
         raise LmxError("stem_conv: out must be a dense NHWC tensor")
-    check(_lib.load().lmx_k_stem_conv(_ptr(img_u8), _ptr(w), _ptr(bias), _ptr(out), n, H, W, Cout, _stream()),
+    check(_lib.load().lmx_k_stem_conv(_ptr(img_u8), _ptr(w), _ptr(bias), _ptr(out), n, H, W, Cout, _stream(dev)),
           "lmx_k_stem_conv")
     return out
 
 
 def maxpool5(x, out):
+    dev = _dev(x, out)
     n, H, W, Cc, ps = _nhwc(x, "maxpool5 x")
     no, Ho, Wo, Co, pso = _nhwc(out, "maxpool5 out")
     if (no, Ho, Wo, Co) != (n, H, W, Cc):
         raise LmxError("maxpool5: shape mismatch")
-    check(_lib.load().lmx_k_maxpool5(_ptr(x), ps, _ptr(out), pso, n, H, W, Cc, _stream()), "lmx_k_maxpool5")
+    check(_lib.load().lmx_k_maxpool5(_ptr(x), ps, _ptr(out), pso, n, H, W, Cc, _stream(dev)), "lmx_k_maxpool5")
     return out
 
 
 def upsample2(x, out):
+    dev = _dev(x, out)
     n, H, W, Cc, ps = _nhwc(x, "upsample2 x")
     no, Ho, Wo, Co, pso = _nhwc(out, "upsample2 out")
     if (no, Ho, Wo, Co) != (n, 2 * H, 2 * W, Cc):
         raise LmxError("upsample2: shape mismatch")
-    check(_lib.load().lmx_k_upsample2(_ptr(x), ps, _ptr(out), pso, n, H, W, Cc, _stream()), "lmx_k_upsample2")
+    check(_lib.load().lmx_k_upsample2(_ptr(x), ps, _ptr(out), pso, n, H, W, Cc, _stream(dev)), "lmx_k_upsample2")
+    return out
+
+
+# ---- the exact plan's x3 format (csrc/exact.hip): a value travels as the f16 channel triple [hi | lo | hi] per group ----------
+def split3(x, act, out3, g=None, res3=None):
+    """f32 NHWC x [n,H,W,N] (channel slices allowed) -> x3 groups of width g written into out3 [n,H,W,3N] (a channel slice of
+    an x3 buffer); y = act(x) + value(res3) (lmx_k_split3)."""
+    dev = _dev(x, out3, res3)
+    n, H, W, N, ps = _nhwc(x, "split3 x")
+    no, Ho, Wo, C3, pso = _nhwc(out3, "split3 out")
+    g = g or N
+    if x.dtype != torch.float32 or out3.dtype != torch.float16 or (no, Ho, Wo, C3) != (n, H, W, 3 * N):
+        raise LmxError(f"split3: x f32 {tuple(x.shape)} -> out3 f16 {tuple(out3.shape)} (3x the channels) expected")
+    ldr = 0
+    if res3 is not None:
+        nr, Hr, Wr, Cr, ldr = _nhwc(res3, "split3 res")
+        if (nr, Hr, Wr, Cr) != (n, H, W, 3 * N) or res3.dtype != torch.float16:
+            raise LmxError("split3: residual must be an x3 tensor of the output's shape")
+    check(_lib.load().lmx_k_split3(_ptr(x), ps, act, _ptr(res3), ldr, _ptr(out3), pso, n * H * W, N, g, _stream(dev)), "lmx_k_split3")
+    return out3
+
+
+def maxpool5_x3(x3, out3):
+    dev = _dev(x3, out3)
+    n, H, W, C3, ps = _nhwc(x3, "maxpool5_x3 x")
+    no, Ho, Wo, Co, pso = _nhwc(out3, "maxpool5_x3 out")
+    if (no, Ho, Wo, Co) != (n, H, W, C3) or C3 % 3:
+        raise LmxError("maxpool5_x3: shape mismatch")
+    check(_lib.load().lmx_k_maxpool5_x3(_ptr(x3), ps, _ptr(out3), pso, n, H, W, C3 // 3, _stream(dev)), "lmx_k_maxpool5_x3")
+    return out3
+
+
+def stem_conv_x3(img_u8, w, bias):
+    dev = _dev(img_u8, w, bias)
+    n, H, W, _ = img_u8.shape
+    Cout = bias.numel()
+    out = torch.empty((n, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 3 * Cout), dtype=torch.float16, device=img_u8.device)
+    check(_lib.load().lmx_k_stem_conv_x3(_ptr(img_u8), _ptr(w), _ptr(bias), _ptr(out), n, H, W, Cout, _stream(dev)),
+          "lmx_k_stem_conv_x3")
     return out
 
 
 def detect_decode(head, pred, nc, stride, a_off):
     """head f32 [n,H,W,ldh] dense, pred f32 [n,A,4+nc] dense."""
-    _dev(head, pred)
+    dev = _dev(head, pred)
     n, H, W, ldh = head.shape
     A = pred.shape[1]
     if not head.is_contiguous() or not pred.is_contiguous() or pred.shape[2] != 4 + nc:
         raise LmxError("detect_decode: head/pred must be dense")
-    check(_lib.load().lmx_k_detect_decode(_ptr(head), ldh, _ptr(pred), n, H, W, nc, float(stride), a_off, A, _stream()),
+    check(_lib.load().lmx_k_detect_decode(_ptr(head), ldh, _ptr(pred), n, H, W, nc, float(stride), a_off, A, _stream(dev)),
           "lmx_k_detect_decode")
     return pred
 
 
 def scale_boxes(boxes, padx, pady, gain, w, h):
-    _dev(boxes)
+    dev = _dev(boxes)
     if boxes.dtype != torch.float32 or not boxes.is_contiguous() or boxes.shape[-1] != 4:
         raise LmxError("scale_boxes: boxes must be dense float32 [...,4]")
     check(_lib.load().lmx_k_scale_boxes(_ptr(boxes), boxes.numel() // 4, float(padx), float(pady), float(gain), float(w),
-                                        float(h), _stream()), "lmx_k_scale_boxes")
+                                        float(h), _stream(dev)), "lmx_k_scale_boxes")
     return boxes
 
 
 def pose_gather(raws, strides, src, counts, kpt_shape, padx, pady, gain, w, h):
     """Keypoints of the detections NMS kept: raws = the three levels' cv4 outputs f32 [n,h,w,ldk]; src / counts from nms().
     -> f32 [n, max_det, K, ndim] in frame pixels (lmx_k_pose_gather)."""
-    _dev(*raws, src, counts)
+    dev = _dev(*raws, src, counts)
     K_, ndim = kpt_shape
     ldk = raws[0].shape[-1]
     for r in raws:
@@ -445,13 +493,13 @@ def pose_gather(raws, strides, src, counts, kpt_shape, padx, pady, gain, w, h):
     out = torch.empty((n, max_det, K_, ndim), dtype=torch.float32, device=src.device)
     check(_lib.load().lmx_k_pose_gather(_ptr(raws[0]), _ptr(raws[1]), _ptr(raws[2]), ldk, C.cast(hw, C.c_void_p),
                                         C.cast(st, C.c_void_p), _ptr(src), _ptr(counts), n, max_det, K_, ndim, float(padx),
-                                        float(pady), float(gain), float(w), float(h), _ptr(out), _stream()), "lmx_k_pose_gather")
+                                        float(pady), float(gain), float(w), float(h), _ptr(out), _stream(dev)), "lmx_k_pose_gather")
     return out
 
 
 def add_bcast(a, b, out=None, out_dtype=torch.float32):
     """out[r] = a[r] + b[r % b_rows]  (a, b float32 2-D; out float32 or float16)."""
-    _dev(a, b, out)
+    dev = _dev(a, b, out)
     rows, D_, lda = _rows(a, "add_bcast a")
     b_rows, Db, ldb = _rows(b, "add_bcast b")
     if Db != D_ or a.dtype not in _DT or b.dtype != torch.float32:
@@ -459,36 +507,36 @@ def add_bcast(a, b, out=None, out_dtype=torch.float32):
     if out is None:
         out = torch.empty((rows, D_), dtype=out_dtype, device=a.device)
     check(_lib.load().lmx_k_add_bcast(_ptr(a), _DT[a.dtype], lda, _ptr(b), ldb, b_rows, _ptr(out), _DT[out.dtype], out.stride(0),
-                                      rows, D_, _stream()), "lmx_k_add_bcast")
+                                      rows, D_, _stream(dev)), "lmx_k_add_bcast")
     return out
 
 
 def prompt_box(boxes, sx, sy, S, gauss, corner):
     """boxes f32 [n,>=4] (row stride allowed) in frame pixels -> sparse f32 [n,2,2F] (lmx_k_prompt_box)."""
-    _dev(boxes, gauss, corner)
+    dev = _dev(boxes, gauss, corner)
     n = boxes.shape[0]
     Fq = gauss.shape[1]
     out = torch.empty((n, 2, 2 * Fq), dtype=torch.float32, device=boxes.device)
     check(_lib.load().lmx_k_prompt_box(_ptr(boxes), boxes.stride(0), _ptr(out), n, float(sx), float(sy), float(S), _ptr(gauss),
-                                       _ptr(corner), Fq, _stream()), "lmx_k_prompt_box")
+                                       _ptr(corner), Fq, _stream(dev)), "lmx_k_prompt_box")
     return out
 
 
 def hyper_mask(up, hyper, n, G, C_):
-    _dev(up, hyper)
+    dev = _dev(up, hyper)
     logits = torch.empty((n, 4 * G, 4 * G), dtype=torch.float32, device=up.device)
-    check(_lib.load().lmx_k_hyper_mask(_ptr(up), _ptr(hyper), _ptr(logits), n, G, C_, _stream()), "lmx_k_hyper_mask")
+    check(_lib.load().lmx_k_hyper_mask(_ptr(up), _ptr(hyper), _ptr(logits), n, G, C_, _stream(dev)), "lmx_k_hyper_mask")
     return logits
 
 
 def mask_post(logits, T, nh, nw, h, w):
     """-> (mask u8 [n,h,w], stats int64 [n,8] = area, sum_x, sum_y, min_x, min_y, max_x, max_y, 0)."""
-    _dev(logits)
+    dev = _dev(logits)
     n, L, _ = logits.shape
     mask = torch.empty((n, h, w), dtype=torch.uint8, device=logits.device)
     stats = torch.empty((n, 8), dtype=torch.int64, device=logits.device)
     ws = torch.empty((n, nh, nw), dtype=torch.float32, device=logits.device)
-    check(_lib.load().lmx_k_mask_post(_ptr(logits), n, L, T, nh, nw, h, w, _ptr(mask), _ptr(stats), _ptr(ws), _stream()),
+    check(_lib.load().lmx_k_mask_post(_ptr(logits), n, L, T, nh, nw, h, w, _ptr(mask), _ptr(stats), _ptr(ws), _stream(dev)),
           "lmx_k_mask_post")
     return mask, stats
 
@@ -496,14 +544,14 @@ def mask_post(logits, T, nh, nw, h, w):
 def contour_features(mask):
     """mask u8 [n,h,w] (0 / non-0) on device -> int64 [n,8] = 2*contourArea, unit steps, diagonal steps, min x, min y, max x,
     max y, number of external contours of the largest external contour (lmx_k_contour_features, csrc/contour.hip)."""
-    _dev(mask)
+    dev = _dev(mask)
     if mask.dtype != torch.uint8 or mask.dim() != 3 or not mask.is_contiguous():
         raise LmxError("contour_features: mask must be contiguous uint8 [n,h,w]")
     n, h, w = mask.shape
     lib = _lib.load()
     ws = torch.empty((int(lib.lmx_contour_workspace_bytes(n, h, w)),), dtype=torch.uint8, device=mask.device)
     out = torch.empty((n, 8), dtype=torch.int64, device=mask.device)
-    check(lib.lmx_k_contour_features(_ptr(mask), n, h, w, _ptr(out), _ptr(ws), _stream()), "lmx_k_contour_features")
+    check(lib.lmx_k_contour_features(_ptr(mask), n, h, w, _ptr(out), _ptr(ws), _stream(dev)), "lmx_k_contour_features")
     return out
 
 
@@ -573,7 +621,7 @@ def _install_trace():
             if LAUNCH_TRACE is None:
                 return fn(*args)
             cls, fl, by, key = _work(name, args)
-            st = torch.cuda.current_stream(_cur_dev)
+            st = torch.cuda.current_stream(_tls.dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             rc = fn(*args)

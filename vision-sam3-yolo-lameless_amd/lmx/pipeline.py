@@ -8,7 +8,7 @@ import torch
 from . import dino, sam, sam_decoder, yolo
 from . import kernels as K
 
-GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")  # package data: BatchNorm statistics of the synthetic YOLO weights
 
 
 def stream_plan(n_chunks, max_streams=4, layout="lanes"):
@@ -37,7 +37,7 @@ class FusedExtractor:
         self.max_streams = int(os.environ.get("LMX_MAX_STREAMS", "7"))
         self.stream_layout = os.environ.get("LMX_STREAM_LAYOUT", "lanes")
         ycfg = yolo.YoloConfig(yolo_scale)
-        bn = yolo_bn or os.path.join(GOLDEN, f"yolov8{yolo_scale}_bn_w{weight_seeds[0]}.npz")
+        bn = yolo_bn or os.path.join(DATA, f"yolov8{yolo_scale}_bn_w{weight_seeds[0]}.npz")
         self.yolo = yolo.YoloDetector(ycfg, yolo.synthetic_state_dict(ycfg, weight_seeds[0], bn if os.path.exists(bn) else None),
                                       self.device)
         scfg = sam.hiera_b_plus()
@@ -65,16 +65,18 @@ class FusedExtractor:
             pool.append(torch.cuda.Stream(self.device))
         return pool[:k]
 
-    def step(self, frames, conf=0.5, sam_chunk=16, keep_byte_masks=False, det_idx=None, emb_idx=None):
+    def step(self, frames, conf=0.5, sam_chunk=16, keep_byte_masks=False, det_idx=None, emb_idx=None, yolo_precision=None):
         """frames u8 [n,1080,1920,3] BGR on device -> dict of device tensors for every frame.  Masks are returned bit-packed
         ([n, h, ceil(w/8)], numpy.packbits order): that is what is gathered across GPUs and copied to the host;
         `keep_byte_masks` adds the u8 [n,h,w] masks the kernels produced.
         Dense schedule (default): every frame goes through all three networks.  Reference schedule: `det_idx` / `emb_idx`
         (index lists into `frames`) name the frames YOLO + SAM resp. DINO run on (yolo main.py:74, dinov3 main.py:127); the
-        outputs keep n rows, zero where a network did not run, plus `ran_det` / `ran_emb` flags."""
+        outputs keep n rows, zero where a network did not run, plus `ran_det` / `ran_emb` flags.
+        yolo_precision: None = the detector's default plan ("exact": keep-sets of the fp32 path, what the services' JSON must
+        carry) or "f16" (the throughput plan; bench.py's dense step) — lmx.yolo.YoloDetector."""
         n = frames.shape[0]
         if det_idx is None and emb_idx is None:
-            return self._step_dense(frames, conf, sam_chunk, keep_byte_masks)
+            return self._step_dense(frames, conf, sam_chunk, keep_byte_masks, yolo_precision=yolo_precision)
         dev = frames.device
         di = torch.as_tensor(list(range(n)) if det_idx is None else list(det_idx), dtype=torch.int64, device=dev)
         ei = torch.as_tensor(list(range(n)) if emb_idx is None else list(emb_idx), dtype=torch.int64, device=dev)
@@ -88,7 +90,7 @@ class FusedExtractor:
                    ran_det=torch.zeros((n,), dtype=torch.int32, device=dev), ran_emb=torch.zeros((n,), dtype=torch.int32, device=dev))
         fd = frames if det_idx is None else frames.index_select(0, di)
         fe = frames if emb_idx is None else frames.index_select(0, ei)
-        part = self._step_dense(fd, conf, sam_chunk, keep_byte_masks, emb_frames=fe)
+        part = self._step_dense(fd, conf, sam_chunk, keep_byte_masks, emb_frames=fe, yolo_precision=yolo_precision)
         if di.numel():
             for k in ("boxes", "scores", "cls", "counts", "mask_bits", "mask_stats", "mask_contour", "mask_iou"):
                 out[k].index_copy_(0, di, part[k].to(out[k].dtype))
@@ -101,7 +103,7 @@ class FusedExtractor:
             out["ran_emb"].index_fill_(0, ei, 1)
         return out
 
-    def _step_dense(self, frames, conf, sam_chunk, keep_byte_masks, emb_frames=None):
+    def _step_dense(self, frames, conf, sam_chunk, keep_byte_masks, emb_frames=None, yolo_precision=None):
         """YOLO -> top-1 box -> SAM on every frame of `frames`; DINO on every frame of `emb_frames` (default: the same)."""
         n, h, w, _ = frames.shape
         emb_frames = frames if emb_frames is None else emb_frames
@@ -127,7 +129,7 @@ class FusedExtractor:
                 boxes, scores, cls, counts = (z((0, 300, 4), device=self.device), z((0, 300), device=self.device),
                                               z((0, 300), dtype=torch.int32, device=self.device), z((0,), dtype=torch.int32, device=self.device))
             else:
-                boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf)
+                boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf, precision=yolo_precision)
             det_done = torch.cuda.Event()
             det_done.record(det_stream)
         with torch.cuda.stream(emb_stream):

@@ -154,29 +154,49 @@ class FusedFeatureService:
     async def process_video(self, video_data):
         video_id = video_data["video_id"]
         processed_path = Path(video_data["processed_path"])
-        if not processed_path.exists():
-            print(f"Processed video not found: {processed_path}")
-            return
+        multi = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+        rank, world = (tdist.get_rank(), tdist.get_world_size()) if multi else (0, 1)
+        # The local pass has its own try block: whatever happens on this rank (missing file, decode error, OOM, LmxError), it
+        # still reaches the control all-reduce below, which carries an error flag beside the row count.  A rank that returned
+        # early would leave its peers blocked in the collective forever.
+        clip = rec = None
+        failed = 0
         try:
-            multi = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
-            rank, world = (tdist.get_rank(), tdist.get_world_size()) if multi else (0, 1)
-            clip = R.Clip.open(processed_path)          # ONE open, ONE decode pass per rank
-            parts = self._run_clip(clip, rank, world)
-            rec = self._concat(parts, self._empty_template(clip))
+            if not processed_path.exists():
+                print(f"Processed video not found: {processed_path}")
+                failed = 1
+            else:
+                clip = R.Clip.open(processed_path)          # ONE open, ONE decode pass per rank
+                parts = self._run_clip(clip, rank, world)
+                rec = self._concat(parts, self._empty_template(clip))
+        except Exception as e:  # noqa: BLE001 — like the services, never raise out of the handler
+            print(f"Error in fused pipeline for {video_id}: {e}")
+            traceback.print_exc()
+            failed = 1
+        try:
             if multi:
-                # every rank must contribute equally many rows: agree on the largest shard (8 bytes of control traffic),
-                # then ONE gather of the packed records
-                n_local = torch.tensor([int(rec["frame_id"].shape[0])], dtype=torch.int64)
+                # every rank must contribute equally many rows: agree on the largest shard AND on whether anybody failed
+                # (16 bytes of control traffic, one all-reduce), then ONE gather of the packed records — or none at all,
+                # on every rank together, when a rank failed (then no file is written and nothing is published, as in the
+                # single-process case)
+                ctl = torch.tensor([0 if rec is None else int(rec["frame_id"].shape[0]), failed], dtype=torch.int64)
                 if tdist.get_backend() != "gloo":
-                    n_local = n_local.cuda()
-                tdist.all_reduce(n_local, op=tdist.ReduceOp.MAX)
-                buf, layout = ldist.pack_records(rec, int(n_local))
+                    ctl = ctl.to(torch.device(self.fx.device))
+                tdist.all_reduce(ctl, op=tdist.ReduceOp.MAX)
+                n_rows, any_failed = (int(v) for v in ctl.tolist())
+                if any_failed:
+                    if not failed:
+                        print(f"Fused pipeline for {video_id}: another rank failed; nothing is written")
+                    return
+                buf, layout = ldist.pack_records(rec, n_rows)
                 g = ldist.gather_packed(buf, root=0)
                 if g is None:
                     return
                 rec = ldist.unpack_records(g, layout)
+            elif failed:
+                return
             await self._emit(video_data, clip, rec)
-        except Exception as e:  # noqa: BLE001 — like the services, never raise out of the handler
+        except Exception as e:  # noqa: BLE001
             print(f"Error in fused pipeline for {video_id}: {e}")
             traceback.print_exc()
 

@@ -38,6 +38,11 @@ def synth_clip(seed, n_frames=150, h=1080, w=1920, start=0):
     return out
 
 
+def cfg1_frame(size=640):
+    """BASELINE cfg#1 input: `np.random.default_rng(0).integers(0, 256, (640, 640, 3), uint8)`."""
+    return np.random.default_rng(0).integers(0, 256, (size, size, 3), dtype=np.uint8)
+
+
 def cfg2_frames(n=32, seed=1, size=640):
     """BASELINE cfg#2 input: uniform u8 noise + 8 pasted solid rectangles per image, BGR u8 [n,640,640,3]."""
     rng = np.random.default_rng(seed)

@@ -153,9 +153,16 @@ def param_spec(cfg):
     return s
 
 
+def bn_stats_path(scale, seed=7, pose=False):
+    """Package data (lmx/data/): BatchNorm running statistics that belong to the synthetic weights of (scale, seed)."""
+    import os
+
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"yolov8{scale}{'-pose' if pose else ''}_bn_w{seed}.npz")
+
+
 def synthetic_state_dict(cfg, seed, bn_stats=None):
-    """Synthetic YOLOv8 weights: the seeded generator plus (optionally) committed BatchNorm running statistics
-    (tests/golden/yolov8*_bn_w*.npz, produced once on the CPU by tests/golden/make_golden.py): random Conv+SiLU stacks
+    """Synthetic YOLOv8 weights: the seeded generator plus (optionally) BatchNorm running statistics (package data
+    lmx/data/yolov8*_bn_w*.npz, produced once on the CPU by tests/golden/make_golden.py): random Conv+SiLU stacks
     are not stable over ~60 layers without the statistics a trained BatchNorm carries."""
     from . import weights
 
@@ -217,11 +224,115 @@ def count_params_flops(cfg, h=640, w=640):
     return params, macs
 
 
-class YoloDetector:
-    """Device-resident fused YOLOv8.  ``detect(frames_bgr_u8)`` reproduces the predictor call per frame, batched."""
+def split_rows_x3(w2, groups):
+    """Exact plan, weight side (csrc/exact.hip): f32 rows w2 [N, K] whose K columns are `groups` consecutive channel groups ->
+    (f16 [N, 3K] = per group [whi | whi / 2048 | wlo], scale f32 [N] = 2^-e, e) with whi + wlo the two-term f16 split of the row
+    pre-scaled by 2^e (its largest weight lands in (2^13, 2^14]: wlo stays a normal f16 for every weight within 2^-12 of it)."""
+    w2 = np.asarray(w2, np.float32)
+    assert sum(groups) == w2.shape[1], (groups, w2.shape)
+    amax = np.abs(w2).max(axis=1)
+    e = np.where(amax > 0, 14 - np.ceil(np.log2(np.maximum(amax, 1e-30))), 0).astype(np.int32)
+    ws = np.ldexp(w2, e[:, None]).astype(np.float32)
+    whi = ws.astype(np.float16)
+    wlo = (ws - whi.astype(np.float32)).astype(np.float16)
+    wmid = (whi.astype(np.float32) / np.float32(2048)).astype(np.float16)
+    parts, o = [], 0
+    for g in groups:
+        parts += [whi[:, o:o + g], wmid[:, o:o + g], wlo[:, o:o + g]]
+        o += g
+    return np.ascontiguousarray(np.concatenate(parts, 1)), np.ldexp(np.float32(1), -e).astype(np.float32), e
 
-    def __init__(self, cfg, state_dict, device="cuda", names=None):
+
+class _PlanF16:
+    """Throughput plan: NHWC f16 activations, one launch per convolution (bias + SiLU + shortcut in the GEMM epilogue)."""
+    cm = 1  # stored f16 channels per logical channel
+
+    def __init__(self, det):
+        self.w = det.w
+
+    def stem(self, img):
+        return K.stem_conv(img, *self.w["model.0"])
+
+    def conv3(self, x, name, stride=1, res=None, out=None):
+        return K.conv3x3(x, *self.w[name], act=K.ACT_SILU, stride=stride, res=res, out=out)
+
+    def conv1(self, x, name, out=None, groups=None, g_out=None):
+        return K.conv1x1(x, *self.w[name], act=K.ACT_SILU, out=out)
+
+    def head(self, x, name, out=None):
+        """the plain Conv2d(c, n_out, 1) that ends a Detect / Pose branch: f32 out, no activation"""
+        return K.conv1x1(x, *self.w[name], act=K.ACT_NONE, out=out, out_dtype=torch.float32)
+
+    pool5 = staticmethod(K.maxpool5)
+    up2 = staticmethod(K.upsample2)
+
+
+class _PlanExact:
+    """Exact plan (csrc/exact.hip): activations travel as x3 triples, every convolution is ONE launch of the same GEMM /
+    implicit-GEMM kernel over K' = 3K with f32 output, followed by lmx_k_split3 (activation, shortcut, re-split)."""
+    cm = 3
+
+    def __init__(self, det):
+        self.det = det
+        self.wx = {}
+
+    def _w(self, name, groups=None):
+        if name not in self.wx:
+            dev = self.det.device
+            w, b = self.det.wf32[name]
+            if w.ndim == 4:  # [Cout, Cin, 3, 3] -> per tap [hi | mid | lo]
+                co, ci = w.shape[:2]
+                x3, sc, e = split_rows_x3(np.transpose(w, (0, 2, 3, 1)).reshape(co, 9 * ci), [ci] * 9)
+            else:
+                x3, sc, e = split_rows_x3(w, groups or [w.shape[1]])
+            self.wx[name] = (torch.from_numpy(x3).to(dev), torch.from_numpy(np.ldexp(b, e).astype(np.float32)).to(dev),
+                             torch.from_numpy(sc).to(dev))
+        return self.wx[name]
+
+    def stem(self, img):
+        return K.stem_conv_x3(img, *self.det.w["model.0"])
+
+    def conv3(self, x, name, stride=1, res=None, out=None):
+        w, b, sc = self._w(name)
+        t = K.conv3x3(x, w, b, act=K.ACT_NONE, stride=stride, scale=sc, out_dtype=torch.float32)
+        if out is None:
+            out = torch.empty(t.shape[:3] + (3 * t.shape[3],), dtype=torch.float16, device=t.device)
+        return K.split3(t, K.ACT_SILU, out, res3=res)
+
+    def conv1(self, x, name, out=None, groups=None, g_out=None):
+        w, b, sc = self._w(name, groups)
+        t = K.conv1x1(x, w, b, act=K.ACT_NONE, scale=sc, out_dtype=torch.float32)
+        if out is None:
+            out = torch.empty(t.shape[:3] + (3 * t.shape[3],), dtype=torch.float16, device=t.device)
+        return K.split3(t, K.ACT_SILU, out, g=g_out)
+
+    def head(self, x, name, out=None):
+        w, b, sc = self._w(name)
+        return K.conv1x1(x, w, b, act=K.ACT_NONE, scale=sc, out=out, out_dtype=torch.float32)
+
+    pool5 = staticmethod(K.maxpool5_x3)
+    up2 = staticmethod(K.upsample2)  # a copy: 3x the channels
+
+
+PRECISIONS = ("f16", "exact")
+
+
+class YoloDetector:
+    """Device-resident fused YOLOv8.  ``detect(frames_bgr_u8)`` reproduces the predictor call per frame, batched.
+
+    Two plans over the same kernels (``precision``):
+      "exact" (default; services, adapters, the reference schedule): 22-bit operands through the f16 MFMA kernels (x3 format,
+              csrc/exact.hip) — the prediction tensor agrees with the fp32 CPU path to ~1e-6, so NMS keep-sets and box
+              indices are those of the fp32 path (north_star); 3x the MFMA work of
+      "f16"   (the dense throughput schedule): f16 activations, scores within ~5e-3 of fp32.
+    The plan is a property of the SCHEDULE, chosen by the caller — never of the batch size, so that a frame's result does
+    not depend on how a clip is sharded over GPUs."""
+
+    def __init__(self, cfg, state_dict, device="cuda", names=None, precision="exact"):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision {precision!r}: expected one of {PRECISIONS}")
         self.cfg = cfg
+        self.precision = precision
         self.device = torch.device(device)
         self.names = {i: n for i, n in enumerate(names if names is not None else
                                                  (COCO_NAMES if cfg.nc == 80 else [f"class_{i}" for i in range(cfg.nc)]))}
@@ -229,16 +340,22 @@ class YoloDetector:
         self.nc_pad = (cfg.nc + 3) // 4 * 4
         sd = state_dict
         dev = self.device
+        self.wf32 = {}  # name -> (folded f32 weight [Cout,Cin,3,3] or [Cout,Cin], f32 bias): the exact plan splits these lazily
 
-        def pack3(name):  # 3x3 conv -> [Cout, (ky,kx,ci)] f16 + f32 bias
-            w, b = fold_bn(sd, name)
+        def pack3(name, wb=None):  # 3x3 conv -> [Cout, (ky,kx,ci)] f16 + f32 bias
+            w, b = wb if wb is not None else fold_bn(sd, name)
+            self.wf32[name] = (w, b)
             wp = np.transpose(w, (0, 2, 3, 1)).reshape(w.shape[0], -1)
             return (torch.from_numpy(np.ascontiguousarray(wp)).to(dev).half().contiguous(), torch.from_numpy(b).to(dev))
 
-        def pack1(name):
-            w, b = fold_bn(sd, name)
-            return (torch.from_numpy(np.ascontiguousarray(w[:, :, 0, 0])).to(dev).half().contiguous(),
-                    torch.from_numpy(b).to(dev))
+        def pack1(name, wb=None):
+            if wb is None:
+                w, b = fold_bn(sd, name)
+                w = np.ascontiguousarray(w[:, :, 0, 0])
+            else:
+                w, b = wb
+            self.wf32[name] = (w, b)
+            return (torch.from_numpy(w).to(dev).half().contiguous(), torch.from_numpy(b).to(dev))
 
         self.w = {}
         for i, m in enumerate(self.table):
@@ -269,8 +386,7 @@ class YoloDetector:
                         if br == "cv3" and self.nc_pad != cfg.nc:  # pad class rows to a multiple of 4 (GEMM N%4)
                             w = np.concatenate([w, np.zeros((self.nc_pad - cfg.nc, w.shape[1]), np.float32)], 0)
                             b = np.concatenate([b, np.zeros((self.nc_pad - cfg.nc,), np.float32)], 0)
-                        self.w[p + f".{br}.{l}.2"] = (torch.from_numpy(np.ascontiguousarray(w)).to(dev).half().contiguous(),
-                                                      torch.from_numpy(b).to(dev))
+                        self.w[p + f".{br}.{l}.2"] = pack1(p + f".{br}.{l}.2", (np.ascontiguousarray(w), b))
                 if cfg.kpt_shape is not None:
                     # Pose branch: c4 = max(ch[0]//4, nk) is not a multiple of 8 in general (51 for 17x3 keypoints): zero-pad
                     # the channels (SiLU(0) = 0, so padded channels stay zero through the branch)
@@ -284,8 +400,7 @@ class YoloDetector:
                         wz[:w.shape[0], :w.shape[1]] = w
                         bz = np.zeros((cout_pad,), np.float32)
                         bz[:b.shape[0]] = b
-                        wp = np.transpose(wz, (0, 2, 3, 1)).reshape(cout_pad, -1)
-                        return (torch.from_numpy(np.ascontiguousarray(wp)).to(dev).half().contiguous(), torch.from_numpy(bz).to(dev))
+                        return pack3(name, (wz, bz))
 
                     for l, x in enumerate(m["ch"]):
                         self.w[p + f".cv4.{l}.0"] = padded3(p + f".cv4.{l}.0", x, c4p)
@@ -294,43 +409,54 @@ class YoloDetector:
                         wz[:nk, :c4] = sd[p + f".cv4.{l}.2.weight"][:, :, 0, 0]
                         bz = np.zeros((self.nk_pad,), np.float32)
                         bz[:nk] = sd[p + f".cv4.{l}.2.bias"]
-                        self.w[p + f".cv4.{l}.2"] = (torch.from_numpy(wz).to(dev).half().contiguous(), torch.from_numpy(bz).to(dev))
+                        self.w[p + f".cv4.{l}.2"] = pack1(p + f".cv4.{l}.2", (wz, bz))
         self._tabs = {}
+        self._plans = {"f16": _PlanF16(self)}
+
+    def _plan(self, precision):
+        precision = precision or self.precision
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision {precision!r}: expected one of {PRECISIONS}")
+        if precision not in self._plans:
+            self._plans[precision] = _PlanExact(self)
+        return self._plans[precision]
 
     # ---- network --------------------------------------------------------------------------------------------
-    def _c2f(self, i, m, x, out):
+    def _c2f(self, P, i, m, x, out, groups=None):
         p = f"model.{i}"
         n, H, W, _ = x.shape
-        c = m["c2"] // 2
-        buf = torch.empty((n, H, W, (2 + m["n"]) * c), dtype=torch.float16, device=x.device)
-        K.conv1x1(x, *self.w[p + ".cv1"], act=K.ACT_SILU, out=buf[..., :2 * c])
-        tmp = torch.empty((n, H, W, c), dtype=torch.float16, device=x.device)
+        c, cm = m["c2"] // 2, P.cm
+        buf = torch.empty((n, H, W, cm * (2 + m["n"]) * c), dtype=torch.float16, device=x.device)
+        P.conv1(x, p + ".cv1", out=buf[..., :cm * 2 * c], groups=groups, g_out=c)
+        tmp = torch.empty((n, H, W, cm * c), dtype=torch.float16, device=x.device)
         for j in range(m["n"]):
-            src = buf[..., (1 + j) * c:(2 + j) * c]
-            dst = buf[..., (2 + j) * c:(3 + j) * c]
-            K.conv3x3(src, *self.w[p + f".m.{j}.cv1"], act=K.ACT_SILU, out=tmp)
-            K.conv3x3(tmp, *self.w[p + f".m.{j}.cv2"], act=K.ACT_SILU, res=src if m["shortcut"] else None, out=dst)
-        return K.conv1x1(buf, *self.w[p + ".cv2"], act=K.ACT_SILU, out=out)
+            src = buf[..., cm * (1 + j) * c:cm * (2 + j) * c]
+            dst = buf[..., cm * (2 + j) * c:cm * (3 + j) * c]
+            P.conv3(src, p + f".m.{j}.cv1", out=tmp)
+            P.conv3(tmp, p + f".m.{j}.cv2", res=src if m["shortcut"] else None, out=dst)
+        return P.conv1(buf, p + ".cv2", out=out, groups=[c] * (2 + m["n"]))
 
-    def _sppf(self, i, m, x, out):
+    def _sppf(self, P, i, m, x, out):
         p = f"model.{i}"
         n, H, W, _ = x.shape
-        c_ = m["c1"] // 2
-        buf = torch.empty((n, H, W, 4 * c_), dtype=torch.float16, device=x.device)
-        K.conv1x1(x, *self.w[p + ".cv1"], act=K.ACT_SILU, out=buf[..., :c_])
+        c_, cm = m["c1"] // 2, P.cm
+        buf = torch.empty((n, H, W, cm * 4 * c_), dtype=torch.float16, device=x.device)
+        P.conv1(x, p + ".cv1", out=buf[..., :cm * c_])
         for j in range(3):
-            K.maxpool5(buf[..., j * c_:(j + 1) * c_], buf[..., (j + 1) * c_:(j + 2) * c_])
-        return K.conv1x1(buf, *self.w[p + ".cv2"], act=K.ACT_SILU, out=out)
+            P.pool5(buf[..., cm * j * c_:cm * (j + 1) * c_], buf[..., cm * (j + 1) * c_:cm * (j + 2) * c_])
+        return P.conv1(buf, p + ".cv2", out=out, groups=[c_] * 4)
 
-    def forward_letterboxed(self, img_u8):
+    def forward_letterboxed(self, img_u8, precision=None):
         """u8 RGB letterboxed [n,H,W,3] (H,W multiples of 32) -> pred f32 [n, A, 4+nc] (xywh in input pixels, scores)."""
         cfg, T = self.cfg, self.table
+        P = self._plan(precision)
+        cm = P.cm
         dev = img_u8.device
         n, H, W, _ = img_u8.shape
         f16 = torch.float16
 
         def buf(h, w, c):
-            return torch.empty((n, h, w, c), dtype=f16, device=dev)
+            return torch.empty((n, h, w, cm * c), dtype=f16, device=dev)
 
         c_out = [m.get("c2", 0) for m in T]
         H8, W8, H16, W16, H32, W32 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
@@ -341,24 +467,24 @@ class YoloDetector:
         cat14 = buf(H8, W8, c12 + c4)
         cat17 = buf(H16, W16, c16 + c12)
         cat20 = buf(H32, W32, c19 + c9)
-        x = K.stem_conv(img_u8, *self.w["model.0"])                                            # 0
-        x = K.conv3x3(x, *self.w["model.1"], act=K.ACT_SILU, stride=2)                          # 1
-        x = self._c2f(2, T[2], x, buf(H // 4, W // 4, c_out[2]))                               # 2
-        x = K.conv3x3(x, *self.w["model.3"], act=K.ACT_SILU, stride=2)                          # 3
-        x4 = self._c2f(4, T[4], x, cat14[..., c12:])                                           # 4 -> cat14
-        x = K.conv3x3(x4, *self.w["model.5"], act=K.ACT_SILU, stride=2)                         # 5
-        x6 = self._c2f(6, T[6], x, cat11[..., c9:])                                            # 6 -> cat11
-        x = K.conv3x3(x6, *self.w["model.7"], act=K.ACT_SILU, stride=2)                         # 7
-        x = self._c2f(8, T[8], x, buf(H32, W32, c_out[8]))                                     # 8
-        x9 = self._sppf(9, T[9], x, cat20[..., c19:])                                          # 9 -> cat20
-        K.upsample2(x9, cat11[..., :c9])                                                       # 10, 11
-        x12 = self._c2f(12, T[12], cat11, cat17[..., c16:])                                    # 12 -> cat17
-        K.upsample2(x12, cat14[..., :c12])                                                     # 13, 14
-        p3 = self._c2f(15, T[15], cat14, buf(H8, W8, c_out[15]))                               # 15
-        K.conv3x3(p3, *self.w["model.16"], act=K.ACT_SILU, stride=2, out=cat17[..., :c16])      # 16, 17
-        p4 = self._c2f(18, T[18], cat17, buf(H16, W16, c_out[18]))                             # 18
-        K.conv3x3(p4, *self.w["model.19"], act=K.ACT_SILU, stride=2, out=cat20[..., :c19])      # 19, 20
-        p5 = self._c2f(21, T[21], cat20, buf(H32, W32, c_out[21]))                             # 21
+        x = P.stem(img_u8)                                                                     # 0
+        x = P.conv3(x, "model.1", stride=2)                                                    # 1
+        x = self._c2f(P, 2, T[2], x, buf(H // 4, W // 4, c_out[2]))                            # 2
+        x = P.conv3(x, "model.3", stride=2)                                                    # 3
+        x4 = self._c2f(P, 4, T[4], x, cat14[..., cm * c12:])                                   # 4 -> cat14
+        x = P.conv3(x4, "model.5", stride=2)                                                   # 5
+        x6 = self._c2f(P, 6, T[6], x, cat11[..., cm * c9:])                                    # 6 -> cat11
+        x = P.conv3(x6, "model.7", stride=2)                                                   # 7
+        x = self._c2f(P, 8, T[8], x, buf(H32, W32, c_out[8]))                                  # 8
+        x9 = self._sppf(P, 9, T[9], x, cat20[..., cm * c19:])                                  # 9 -> cat20
+        P.up2(x9, cat11[..., :cm * c9])                                                        # 10, 11
+        x12 = self._c2f(P, 12, T[12], cat11, cat17[..., cm * c16:], groups=[c9, c6])           # 12 -> cat17
+        P.up2(x12, cat14[..., :cm * c12])                                                      # 13, 14
+        p3 = self._c2f(P, 15, T[15], cat14, buf(H8, W8, c_out[15]), groups=[c12, c4])          # 15
+        P.conv3(p3, "model.16", stride=2, out=cat17[..., :cm * c16])                           # 16, 17
+        p4 = self._c2f(P, 18, T[18], cat17, buf(H16, W16, c_out[18]), groups=[c16, c12])       # 18
+        P.conv3(p4, "model.19", stride=2, out=cat20[..., :cm * c19])                           # 19, 20
+        p5 = self._c2f(P, 21, T[21], cat20, buf(H32, W32, c_out[21]), groups=[c19, c9])        # 21
         # Detect
         A = H8 * W8 + H16 * W16 + H32 * W32
         pred = torch.empty((n, A, 4 + cfg.nc), dtype=torch.float32, device=dev)
@@ -369,18 +495,18 @@ class YoloDetector:
             p = f"model.22"
             h, w = feat.shape[1], feat.shape[2]
             head = torch.empty((n, h, w, ldh), dtype=torch.float32, device=dev)
-            t = K.conv3x3(feat, *self.w[p + f".cv2.{l}.0"], act=K.ACT_SILU)
-            t = K.conv3x3(t, *self.w[p + f".cv2.{l}.1"], act=K.ACT_SILU)
-            K.conv1x1(t, *self.w[p + f".cv2.{l}.2"], act=K.ACT_NONE, out=head[..., :64])
-            t = K.conv3x3(feat, *self.w[p + f".cv3.{l}.0"], act=K.ACT_SILU)
-            t = K.conv3x3(t, *self.w[p + f".cv3.{l}.1"], act=K.ACT_SILU)
-            K.conv1x1(t, *self.w[p + f".cv3.{l}.2"], act=K.ACT_NONE, out=head[..., 64:])
+            t = P.conv3(feat, p + f".cv2.{l}.0")
+            t = P.conv3(t, p + f".cv2.{l}.1")
+            P.head(t, p + f".cv2.{l}.2", out=head[..., :64])
+            t = P.conv3(feat, p + f".cv3.{l}.0")
+            t = P.conv3(t, p + f".cv3.{l}.1")
+            P.head(t, p + f".cv3.{l}.2", out=head[..., 64:])
             K.detect_decode(head, pred, cfg.nc, stride, a_off)
             a_off += h * w
             if cfg.kpt_shape is not None:
-                t = K.conv3x3(feat, *self.w[p + f".cv4.{l}.0"], act=K.ACT_SILU)
-                t = K.conv3x3(t, *self.w[p + f".cv4.{l}.1"], act=K.ACT_SILU)
-                kraw.append(K.conv1x1(t, *self.w[p + f".cv4.{l}.2"], act=K.ACT_NONE, out_dtype=torch.float32))
+                t = P.conv3(feat, p + f".cv4.{l}.0")
+                t = P.conv3(t, p + f".cv4.{l}.1")
+                kraw.append(P.head(t, p + f".cv4.{l}.2"))
         if cfg.kpt_shape is not None:
             return pred, kraw
         return pred
@@ -401,12 +527,12 @@ class YoloDetector:
         geo, tabs = self._letterbox_tables(sh, sw)
         return K.letterbox(frames_bgr, geo, tabs, swap_rb=True), geo
 
-    def detect_pose(self, frames_bgr, conf=0.25, iou=0.7, max_det=300):
+    def detect_pose(self, frames_bgr, conf=0.25, iou=0.7, max_det=300, precision=None):
         """Pose models: detect() plus keypoints f32 [n, max_det, K, ndim] in FRAME pixels (x, y, sigmoid visibility)."""
         if self.cfg.kpt_shape is None:
             raise ValueError("detect_pose: the model has no Pose head (YoloConfig.kpt_shape)")
         img, geo = self.preprocess(frames_bgr)
-        pred, kraw = self.forward_letterboxed(img)
+        pred, kraw = self.forward_letterboxed(img, precision)
         boxes, scores, cls, src, counts = K.nms(pred, conf, iou, max_det)
         K.scale_boxes(boxes, geo.pad_x, geo.pad_y, geo.gain, geo.sw, geo.sh)
         # ops.scale_coords subtracts the UNROUNDED padding (scale_boxes rounds it like LetterBox does)
@@ -415,10 +541,11 @@ class YoloDetector:
         kpts = K.pose_gather(kraw, (8, 16, 32), src, counts, self.cfg.kpt_shape, padx, pady, geo.gain, geo.sw, geo.sh)
         return boxes, scores, cls, src, counts, kpts
 
-    def detect(self, frames_bgr, conf=0.25, iou=0.7, max_det=300):
-        """u8 BGR [n,h,w,3] on device -> (boxes [n,max_det,4] xyxy in FRAME pixels, scores, cls, src, counts) on device."""
+    def detect(self, frames_bgr, conf=0.25, iou=0.7, max_det=300, precision=None):
+        """u8 BGR [n,h,w,3] on device -> (boxes [n,max_det,4] xyxy in FRAME pixels, scores, cls, src, counts) on device.
+        precision: None = the detector's default plan, or "exact" / "f16" (class docstring)."""
         img, geo = self.preprocess(frames_bgr)
-        pred = self.forward_letterboxed(img)
+        pred = self.forward_letterboxed(img, precision)
         if self.cfg.kpt_shape is not None:
             pred = pred[0]
         boxes, scores, cls, src, counts = K.nms(pred, conf, iou, max_det)
