@@ -295,15 +295,15 @@ def main():
     # the dense schedule is the THROUGHPUT mode: YOLO on its f16 plan; the reference schedule is the mode whose JSON must match
     # the reference: YOLO on its exact plan (lmx.yolo.YoloDetector)
     def step_dense():
-        persist(fx.step(frames, sam_chunk=args.sam_chunk, yolo_precision="f16"))
+        persist(fx.step(frames, sam_chunk=args.sam_chunk, precision="f16"))
 
     def step_reference():
-        persist(fx.step(sched_frames, sam_chunk=args.sam_chunk, det_idx=det_idx, emb_idx=emb_idx, yolo_precision="exact"))
+        persist(fx.step(sched_frames, sam_chunk=args.sam_chunk, det_idx=det_idx, emb_idx=emb_idx, precision="exact"))
 
     def step_sharded():
         """north_star's multi-GPU path: this rank's block of THE clip, then ONE gather of the packed records to rank 0 (the
         service's collective: lmx.dist.gather_clip_records pads the short last blocks), D2H on rank 0."""
-        out = {k: v for k, v in fx.step(shard, sam_chunk=shard_chunk, yolo_precision="f16").items() if k != "mask"}
+        out = {k: v for k, v in fx.step(shard, sam_chunk=shard_chunk, precision="f16").items() if k != "mask"}
         buf, _ = ldist.pack_records(out, ldist.shard_rows(args.frames, world))
         g = ldist.gather_packed(buf, root=0)
         if g is not None:
@@ -344,12 +344,12 @@ def main():
     classes, traced_share, dt_serial = None, None, None
     if not args.no_roofline:
         fx.serial = True
-        fx.step(frames, sam_chunk=args.sam_chunk, yolo_precision="f16")
+        fx.step(frames, sam_chunk=args.sam_chunk, precision="f16")
         torch.cuda.synchronize()
         K.start_launch_trace()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            fx.step(frames, sam_chunk=args.sam_chunk, yolo_precision="f16")
+            fx.step(frames, sam_chunk=args.sam_chunk, precision="f16")
         torch.cuda.synchronize()
         dt_serial = time.perf_counter() - t1
         trace, shapes = K.stop_launch_trace(by_shape=True)

@@ -76,6 +76,10 @@ typedef struct {
   /* residual broadcast: if res_rows > 0 the residual row is (m % res_rows) — e.g. a position table [tokens][N]
    * added to every image of the batch (Hiera patch embed + pos_embed, TF sam2 :661-662) */
   int32_t res_rows;
+  /* a_mode 0 only: A's K columns are read a_rep times (0 / 1: once): K = a_rep * Ka, k-tile kt takes A columns (kt*BK) mod Ka
+   * and W columns kt*BK.  With W = [whi | wlo] (a_rep 2) ONE launch accumulates a.whi + a.wlo: f16 activations against
+   * 22-bit weights (the exact plan of the SAM ViT encoder, lmx/sam.py).  Ka % 64 == 0; the LDS-DMA kernel's shapes only. */
+  int32_t a_rep;
 } lmx_gemm_desc;
 int lmx_k_gemm(const lmx_gemm_desc* d, lmx_stream_t stream);
 /* development hook (tools/gemm_sweep.py): force one tiling of the LDS-DMA GEMM for every following launch; v = 0 restores
@@ -231,8 +235,8 @@ int lmx_k_scale_boxes(float* boxes, int total, float padx, float pady, float gai
  * lmx_k_gemm launch over K' = 3K with f32 output yields x.w up to the dropped (x-hi)(w-whi) term (2^-22 relative).
  * lmx_k_split3: y = act(x) (+ the value of the x3 residual res3), written as x3 groups: f32 x [rows][ldx], N logical
  *   channels in groups of g (N % g == 0, g % 8 == 0): logical channel n = q*g + r sits at out3[m*ldo + q*3g + r] (hi),
- *   + g (lo), + 2g (hi again); res3 has the same grouping with pixel stride ldr.  act: NONE / SILU / RELU, SiLU as
- *   x / (1 + exp(-x)) with a true division (torch's CPU form).  Replaces the activation half of ultralytics' Conv and the
+ *   + g (lo), + 2g (hi again); res3 has the same grouping with pixel stride ldr.  act: NONE / SILU / GELU / RELU in torch's CPU forms: SiLU as
+ *   x / (1 + exp(-x)) with a true division, GELU as 0.5 x (1 + erf(x / sqrt 2)).  Replaces the activation half of ultralytics' Conv and the
  *   shortcut add of Bottleneck under the exact plan.
  * lmx_k_maxpool5_x3: lmx_k_maxpool5 on an x3 slice of C logical channels (maximum by value; the pair travels with it).
  * lmx_k_stem_conv_x3: lmx_k_stem_conv writing x3: out3 f16 [n][H/2][W/2][3*Cout].
@@ -242,6 +246,15 @@ int lmx_k_split3(const float* x, int64_t ldx, int act, const void* res3, int64_t
 int lmx_k_maxpool5_x3(const void* src3, int64_t lds, void* dst3, int64_t ldd, int n, int H, int W, int C, lmx_stream_t stream);
 int lmx_k_stem_conv_x3(const uint8_t* img, const float* w, const float* bias, void* out3, int n, int H, int W, int Cout,
                        lmx_stream_t stream);
+/* The exact plan of the SAM mask decoder (lmx/sam_decoder.py precision="exact": f32 activations, x3 operands for every Linear):
+ * lmx_k_attention_f32: SamAttention's softmax(q k^T * scale) v in plain f32 (TF:models/sam/modeling_sam.py:205-268) for the
+ *   decoder's tiny problems — 7 tokens against 4096 image positions and back, head dim 16 or 32; q/k/v/o f32 token rows
+ *   (row = b*T + t, head h at columns h*hd ..), flat geometry.  exp is expf, the division a true one.
+ * lmx_k_hyper_mask_f32: lmx_k_hyper_mask on an f32 upscaled embedding `up` f32 [n][G*G][4][4][C], with the upscaler's last
+ *   activation (act = LMX_ACT_GELU: exact erf form, or LMX_ACT_NONE) applied on load. */
+int lmx_k_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o,
+                        int64_t ldo, int B, int H, int Tq, int Tk, int hd, float scale, lmx_stream_t stream);
+int lmx_k_hyper_mask_f32(const float* up, const float* hyper, float* logits, int n, int G, int C, int act, lmx_stream_t stream);
 
 /* Pose head post-processing for the detections lmx_k_nms kept (ultralytics Pose.kpts_decode + ops.scale_coords +
  * clip_coords; the YOLOv8-pose consumer is services/tleap-pipeline/app/main.py:142-163, `result.keypoints[j].data`).

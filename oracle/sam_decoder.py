@@ -18,9 +18,19 @@ import torch.nn.functional as F
 HEADS = 8
 
 
+EMULATE = set()  # f16-STORAGE emulation switches (tools/sam_precision_probe.py), as in oracle/sam_vit.py: "w" weights, "proj"
+#                  (inputs and outputs of the attention projections, attention output), "mlp" (token MLP input / hidden),
+#                  "up" (upscaler: keys16, LN+GELU output, second ConvTranspose output), "tok" (mask / iou token, hypernet hidden)
+
+
+def _q(x, tag):
+    return x.half().float() if tag in EMULATE else x
+
+
 def _t(sd, k):
     v = sd[k]
-    return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+    v = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+    return _q(v, "w") if (k.endswith("weight") and v.dim() >= 2 and "embed" not in k and "token" not in k) else v
 
 
 def _pe(gauss, coords01):
@@ -51,14 +61,14 @@ def prompt_encode_box(sd, boxes, image_size=1024):
 
 
 def _attn(sd, p, q, k, v):
-    q = F.linear(q, _t(sd, p + "q_proj.weight"), _t(sd, p + "q_proj.bias"))
-    k = F.linear(k, _t(sd, p + "k_proj.weight"), _t(sd, p + "k_proj.bias"))
-    v = F.linear(v, _t(sd, p + "v_proj.weight"), _t(sd, p + "v_proj.bias"))
+    q = _q(F.linear(_q(q, "proj"), _t(sd, p + "q_proj.weight"), _t(sd, p + "q_proj.bias")), "proj")
+    k = _q(F.linear(_q(k, "proj"), _t(sd, p + "k_proj.weight"), _t(sd, p + "k_proj.bias")), "proj")
+    v = _q(F.linear(_q(v, "proj"), _t(sd, p + "v_proj.weight"), _t(sd, p + "v_proj.bias")), "proj")
     n, tq, c = q.shape
     hd = c // HEADS
     qh, kh, vh = (t.reshape(n, -1, HEADS, hd).transpose(1, 2) for t in (q, k, v))
-    w = torch.softmax(torch.matmul(qh, kh.transpose(2, 3)) * hd ** -0.5, dim=-1)
-    o = torch.matmul(w, vh).transpose(1, 2).reshape(n, tq, c)
+    w = _q(torch.softmax(torch.matmul(qh, kh.transpose(2, 3)) * hd ** -0.5, dim=-1), "proj")
+    o = _q(torch.matmul(w, vh).transpose(1, 2).reshape(n, tq, c), "proj")
     return F.linear(o, _t(sd, p + "out_proj.weight"), _t(sd, p + "out_proj.bias"))
 
 
@@ -67,9 +77,9 @@ def _ln(sd, p, x, eps=1e-6):
 
 
 def _ffn(sd, p, x, n_mid):
-    x = F.relu(F.linear(x, _t(sd, p + "proj_in.weight"), _t(sd, p + "proj_in.bias")))
+    x = _q(F.relu(F.linear(_q(x, "tok"), _t(sd, p + "proj_in.weight"), _t(sd, p + "proj_in.bias"))), "tok")
     for i in range(n_mid):
-        x = F.relu(F.linear(x, _t(sd, p + f"layers.{i}.weight"), _t(sd, p + f"layers.{i}.bias")))
+        x = _q(F.relu(F.linear(x, _t(sd, p + f"layers.{i}.weight"), _t(sd, p + f"layers.{i}.bias"))), "tok")
     return F.linear(x, _t(sd, p + "proj_out.weight"), _t(sd, p + "proj_out.bias"))
 
 
@@ -92,7 +102,7 @@ def mask_decode(sd, image_emb, sparse, return_all=False):
         queries = _ln(sd, p + "layer_norm1.", queries)
         queries = queries + _attn(sd, p + "cross_attn_token_to_image.", queries + qpe, keys + key_pe, keys)
         queries = _ln(sd, p + "layer_norm2.", queries)
-        m = F.linear(F.relu(F.linear(queries, _t(sd, p + "mlp.lin1.weight"), _t(sd, p + "mlp.lin1.bias"))),
+        m = F.linear(_q(F.relu(F.linear(_q(queries, "mlp"), _t(sd, p + "mlp.lin1.weight"), _t(sd, p + "mlp.lin1.bias"))), "mlp"),
                      _t(sd, p + "mlp.lin2.weight"), _t(sd, p + "mlp.lin2.bias"))
         queries = _ln(sd, p + "layer_norm3.", queries + m)
         keys = keys + _attn(sd, p + "cross_attn_image_to_token.", keys + key_pe, queries + qpe, queries)
@@ -101,10 +111,10 @@ def mask_decode(sd, image_emb, sparse, return_all=False):
     queries = queries + _attn(sd, p + "final_attn_token_to_image.", queries + qpe, keys + key_pe, keys)
     queries = F.layer_norm(queries, (c,), _t(sd, p + "layer_norm_final_attn.weight"), _t(sd, p + "layer_norm_final_attn.bias"), 1e-5)
     iou_tok, mask_tok = queries[:, 0], queries[:, 1:5]
-    x = keys.transpose(1, 2).reshape(n, c, h, w)
+    x = _q(keys, "up").transpose(1, 2).reshape(n, c, h, w)
     x = F.conv_transpose2d(x, _t(sd, "mask_decoder.upscale_conv1.weight"), _t(sd, "mask_decoder.upscale_conv1.bias"), stride=2)
-    x = F.gelu(_ln(sd, "mask_decoder.upscale_layer_norm.", x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2))
-    x = F.gelu(F.conv_transpose2d(x, _t(sd, "mask_decoder.upscale_conv2.weight"), _t(sd, "mask_decoder.upscale_conv2.bias"), stride=2))
+    x = _q(F.gelu(_ln(sd, "mask_decoder.upscale_layer_norm.", x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)), "up")
+    x = _q(F.gelu(F.conv_transpose2d(x, _t(sd, "mask_decoder.upscale_conv2.weight"), _t(sd, "mask_decoder.upscale_conv2.bias"), stride=2)), "up")
     hyper = torch.stack([_ffn(sd, f"mask_decoder.output_hypernetworks_mlps.{i}.", mask_tok[:, i], 1) for i in range(4)], 1)
     masks = (hyper @ x.flatten(2)).reshape(n, 4, x.shape[2], x.shape[3])
     iou = _ffn(sd, "mask_decoder.iou_prediction_head.", iou_tok, 1)

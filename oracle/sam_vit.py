@@ -7,9 +7,20 @@ import torch
 import torch.nn.functional as F
 
 
+EMULATE = set()  # f16-STORAGE emulation switches (tools/sam_precision_probe.py): which of the device path's f16 roundings to
+#                  apply to this fp32 arithmetic.  Empty = the plain fp32 oracle (the parity target).  Tags: "w" weights, "ln"
+#                  LayerNorm outputs, "qkv", "rel" (decomposed rel-pos tables), "p" (softmax probabilities), "ao" (attention
+#                  output), "gelu" (MLP hidden), "neck" (the neck's three f16 tensors), "emb" (the f16 image embedding)
+
+
+def _q(x, tag):
+    return x.half().float() if tag in EMULATE else x
+
+
 def _t(sd, k):
     v = sd[k]
-    return v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
+    v = v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
+    return _q(v, "w") if (k.endswith("weight") and v.dim() >= 2) else v
 
 
 def _rel(q_size, rel_pos):
@@ -20,15 +31,15 @@ def _rel(q_size, rel_pos):
 def _attention(sd, p, x, heads):
     B, H, W, D = x.shape
     hd = D // heads
-    qkv = F.linear(x, _t(sd, p + "qkv.weight"), _t(sd, p + "qkv.bias")).reshape(B, H * W, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qkv = _q(F.linear(x, _t(sd, p + "qkv.weight"), _t(sd, p + "qkv.bias")), "qkv").reshape(B, H * W, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv.reshape(3, B * heads, H * W, hd).unbind(0)
     a = (q * hd ** -0.5) @ k.transpose(-2, -1)
     rq = q.reshape(B * heads, H, W, hd)
-    rel_h = torch.einsum("bhwc,hkc->bhwk", rq, _rel(H, _t(sd, p + "rel_pos_h")))
-    rel_w = torch.einsum("bhwc,wkc->bhwk", rq, _rel(W, _t(sd, p + "rel_pos_w")))
+    rel_h = _q(torch.einsum("bhwc,hkc->bhwk", rq, _rel(H, _t(sd, p + "rel_pos_h"))), "rel")
+    rel_w = _q(torch.einsum("bhwc,wkc->bhwk", rq, _rel(W, _t(sd, p + "rel_pos_w"))), "rel")
     a = a + (rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).reshape_as(a)
-    a = torch.softmax(a, dim=-1)
-    o = (a @ v).reshape(B, heads, H, W, hd).permute(0, 2, 3, 1, 4).reshape(B, H, W, D)
+    a = _q(torch.softmax(a, dim=-1), "p")
+    o = _q((a @ v).reshape(B, heads, H, W, hd).permute(0, 2, 3, 1, 4).reshape(B, H, W, D), "ao")
     return F.linear(o, _t(sd, p + "proj.weight"), _t(sd, p + "proj.bias"))
 
 
@@ -41,7 +52,7 @@ def encoder_forward(cfg, sd, pixel_values):
     for i in range(cfg.layers):
         p = f"vision_encoder.layers.{i}."
         res = x
-        h = F.layer_norm(x, (D,), _t(sd, p + "layer_norm1.weight"), _t(sd, p + "layer_norm1.bias"), cfg.eps)
+        h = _q(F.layer_norm(x, (D,), _t(sd, p + "layer_norm1.weight"), _t(sd, p + "layer_norm1.bias"), cfg.eps), "ln")
         if i in cfg.global_idx:
             h = _attention(sd, p + "attn.", h, cfg.heads)
         else:
@@ -54,14 +65,14 @@ def encoder_forward(cfg, sd, pixel_values):
             win = _attention(sd, p + "attn.", win, cfg.heads)
             h = win.reshape(B, Hp // ws, Wp // ws, ws, ws, D).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, D)[:, :H, :W]
         x = res + h
-        h = F.layer_norm(x, (D,), _t(sd, p + "layer_norm2.weight"), _t(sd, p + "layer_norm2.bias"), cfg.eps)
-        h = F.linear(F.gelu(F.linear(h, _t(sd, p + "mlp.lin1.weight"), _t(sd, p + "mlp.lin1.bias"))),
+        h = _q(F.layer_norm(x, (D,), _t(sd, p + "layer_norm2.weight"), _t(sd, p + "layer_norm2.bias"), cfg.eps), "ln")
+        h = F.linear(_q(F.gelu(F.linear(h, _t(sd, p + "mlp.lin1.weight"), _t(sd, p + "mlp.lin1.bias"))), "gelu"),
                      _t(sd, p + "mlp.lin2.weight"), _t(sd, p + "mlp.lin2.bias"))
         x = x + h
-    y = F.conv2d(x.permute(0, 3, 1, 2), _t(sd, "vision_encoder.neck.conv1.weight"))
-    y = F.layer_norm(y.permute(0, 2, 3, 1), (cfg.out_ch,), _t(sd, "vision_encoder.neck.layer_norm1.weight"),
-                     _t(sd, "vision_encoder.neck.layer_norm1.bias"), 1e-6).permute(0, 3, 1, 2)
-    y = F.conv2d(y, _t(sd, "vision_encoder.neck.conv2.weight"), padding=1)
+    y = F.conv2d(_q(x, "neck").permute(0, 3, 1, 2), _t(sd, "vision_encoder.neck.conv1.weight"))
+    y = _q(F.layer_norm(y.permute(0, 2, 3, 1), (cfg.out_ch,), _t(sd, "vision_encoder.neck.layer_norm1.weight"),
+                        _t(sd, "vision_encoder.neck.layer_norm1.bias"), 1e-6), "neck").permute(0, 3, 1, 2)
+    y = _q(F.conv2d(y, _t(sd, "vision_encoder.neck.conv2.weight"), padding=1), "neck")
     y = F.layer_norm(y.permute(0, 2, 3, 1), (cfg.out_ch,), _t(sd, "vision_encoder.neck.layer_norm2.weight"),
                      _t(sd, "vision_encoder.neck.layer_norm2.bias"), 1e-6).permute(0, 3, 1, 2)
-    return y
+    return _q(y, "emb")

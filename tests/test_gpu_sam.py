@@ -123,9 +123,11 @@ def test_hiera_b_plus_matches_golden(cuda):
     assert cos3 > 1 - 1e-4 and cosh > 1 - 1e-4
 
 
-def test_mask_decoder_matches_oracle(cuda):
+@pytest.mark.parametrize("precision", ["exact", "f16"])
+def test_mask_decoder_matches_oracle(cuda, precision):
     """Prompt encoder + two-way decoder + upscaler + post-processing vs the fp32 oracle on the same embeddings/boxes.
-    Bar (BASELINE.json north_star): mask IoU >= 0.999."""
+    Bar (BASELINE.json north_star): mask IoU >= 0.999 — for both plans; the exact plan (f32 activations, 22-bit operands, f32
+    attention: what the services run) must in addition reproduce the low-res logits to 1e-4 relative."""
     from lmx import kernels as K
     from lmx import sam_decoder
     from oracle import sam_decoder as OD
@@ -143,16 +145,16 @@ def test_mask_decoder_matches_oracle(cuda):
         sp = OD.prompt_encode_box(sd, torch.from_numpy(OD.scale_box(boxes, hw, rhw)))
         low_ref, iou_ref = OD.mask_decode(sd, emb, sp)
         mask_ref = OD.postprocess(low_ref, rhw, hw)
-    dec = sam_decoder.MaskDecoder(sd, cuda)
-    d_emb = emb.permute(0, 2, 3, 1).reshape(n * 4096, 256).contiguous().half().to(cuda)
-    out = dec.predict(d_emb, torch.from_numpy(boxes).to(cuda), hw, rhw)
+    dec = sam_decoder.MaskDecoder(sd, cuda, precision=precision)
+    d_emb = emb.permute(0, 2, 3, 1).reshape(n * 4096, 256).contiguous().to(cuda)
+    out = dec.predict(d_emb if precision == "exact" else d_emb.half(), torch.from_numpy(boxes).to(cuda), hw, rhw)
     torch.cuda.synchronize()
     sparse = K.prompt_box(torch.from_numpy(boxes).to(cuda), rhw[1] / hw[1], rhw[0] / hw[0], 1024.0, dec.gauss, dec.corner).cpu()
     assert float((sparse - sp).abs().max()) < 2e-4
     low = out["lowres"].cpu()
     rel = float((low - low_ref).norm() / low_ref.norm())
-    print("decoder lowres rel err", rel, "iou head", out["iou"].cpu().tolist(), iou_ref.tolist())
-    assert rel < 2e-2
+    print(precision, "decoder lowres rel err", rel, "iou head", out["iou"].cpu().tolist(), iou_ref.tolist())
+    assert rel < (1e-4 if precision == "exact" else 2e-2)
     m = out["mask"].cpu().bool()
     for i in range(n):
         inter = float((m[i] & mask_ref[i]).sum())
@@ -161,7 +163,7 @@ def test_mask_decoder_matches_oracle(cuda):
         frac = float(mask_ref[i].float().mean())
         print(f"mask {i}: IoU {iou:.6f}, coverage {frac:.3f}")
         assert 0.02 < frac < 0.98, "degenerate reference mask: the test would not measure anything"
-        assert iou >= 0.999, f"mask {i}: IoU {iou}"
+        assert iou >= (0.9999 if precision == "exact" else 0.999), f"mask {i}: IoU {iou}"
     # mask_post alone on the oracle's logits: exact same pixels except where |value| ~ 0, and exact statistics
     mk, st = K.mask_post(low_ref.to(cuda), 1024, rhw[0], rhw[1], hw[0], hw[1])
     mk, st = mk.cpu().bool(), st.cpu()
@@ -251,11 +253,11 @@ def test_mask_from_raw_frame_iou(cuda, kind, fixture):
     """north_star bar END TO END (services/sam3-pipeline/app/main.py:80-88: set_image + predict(box) -> masks[0]): raw
     1080p BGR frame + box -> HIP preprocessing -> HIP image encoder (Hiera-B+ = BASELINE cfg#3, SAM v1 ViT-B = the
     reference's own code path) -> HIP prompt encoder + mask decoder + post-processing, against the committed mask of the
-    fp32 oracle run on the same frames (tests/golden/make_golden.py sam_masks).  Bar: mask IoU >= 0.999 for the BASELINE
-    configuration (Hiera-B+; measured 0.99942 / 0.99965).  The ViT-B path measures 0.99909 / 0.99821 on these frames and is
-    held to 0.998: its synthetic-weight masks cover 10-16 % of the frame with shallow logit slopes at the boundary, so the
-    f16 path's 1e-3 relative logit error moves more boundary pixels per mask pixel than on the Hiera masks (73-77 % coverage);
-    stated in DESIGN.md section 4, not hidden."""
+    fp32 oracle run on the same frames (tests/golden/make_golden.py sam_masks).  Bar: mask IoU >= 0.999 for BOTH encoders on
+    the plans the services run (default = "exact": the decoder with f32 activations and 22-bit operands; the ViT encoder with
+    two-term weights).  Round 2 measured 0.99909 / 0.99821 for ViT-B on the all-f16 path; tools/sam_precision_probe.py
+    (profiles/r03_sam_vit_precision_probe.txt) located the error in the decoder (8e-4 of the 9e-4 relative logit error) and
+    the encoder's f16 WEIGHTS (3.9e-4), not in its activations."""
     from lmx import sam, sam_decoder, synth, weights
 
     g = np.load(os.path.join(GOLD, fixture + ".npz"))
@@ -284,7 +286,7 @@ def test_mask_from_raw_frame_iou(cuda, kind, fixture):
     assert emb_cos > 1 - 1e-4
     for i, v in enumerate(ious):
         assert 0.02 < float(g["coverage"][i]) < 0.98
-        assert v >= (0.999 if kind == "hiera_bplus" else 0.998), f"{kind} frame {i}: raw-frame mask IoU {v}"
+        assert v >= 0.999, f"{kind} frame {i}: raw-frame mask IoU {v}"
     # bit-packed output (what the service persists / gathers) decodes to the same mask
     from lmx import kernels as K
     bits = K.pack_bits(out["mask"]).cpu().numpy()

@@ -308,18 +308,37 @@ EXACT_SCORE_EPS = 2e-5   # measured on MI355X: <= 1.01e-5 over every kept detect
 EXACT_BOX_EPS = 5e-3     # letterboxed px on coordinates up to 640 (f32 ulp there: 6e-5)
 
 
+FP32_TIE = 5e-6  # two fp32 scores closer than this have no defined order in the REFERENCE: the fp32 CPU path sits 1e-6 .. 4e-6 from an
+#                  f64 evaluation of itself (tools/fp32_noise_probe.py, profiles/r03_fp32_noise.txt) and reorders with the core count
+
+
 def _assert_keepset_equals_golden(det_out, j, gold, prefix, conf_key, scale_px=1.0):
+    """The device keep-set IS the fp32 golden's: same count, same anchors, same order (np.array_equal).  The one thing that is
+    not a property of the fp32 path itself is the order of two detections whose fp32 scores differ by less than the fp32 path's
+    own rounding noise (FP32_TIE): such neighbours may appear swapped; they are counted, printed and must stay rare.  Nothing
+    else is tolerated: no missing / extra anchor, no class change, no swap across a larger score gap."""
     boxes, scores, cls, src, counts = det_out
-    g_src = gold[f"{prefix}src"]
+    g_src, g_sc = gold[f"{prefix}src"], gold[f"{prefix}scores"]
     k = int(counts[j])
     assert k == len(g_src), f"{prefix}: {k} detections, fp32 golden has {len(g_src)}"
-    assert np.array_equal(src[j, :k], g_src), f"{prefix}: keep-set (anchor indices, in order) differs from the fp32 golden"
+    dev = src[j, :k]
+    ties = 0
+    perm = np.arange(k)
+    if not np.array_equal(dev, g_src):
+        assert sorted(dev.tolist()) == sorted(g_src.tolist()), f"{prefix}: kept anchors differ from the fp32 golden's"
+        where = {int(a): i for i, a in enumerate(g_src)}
+        perm = np.asarray([where[int(a)] for a in dev])
+        moved = np.nonzero(perm != np.arange(k))[0]
+        gap = float(np.abs(g_sc[perm[moved]] - g_sc[moved]).max())
+        assert gap <= FP32_TIE, f"{prefix}: detections {moved.tolist()} are ordered differently across an fp32 score gap of {gap}"
+        ties = len(moved)
+        assert ties <= 4, f"{prefix}: {ties} detections sit in fp32 score ties — too many to call the keep-set pinned"
     if f"{prefix}cls" in gold.files:
-        assert np.array_equal(cls[j, :k], gold[f"{prefix}cls"]), f"{prefix}: classes differ"
-    ds = float(np.abs(scores[j, :k] - gold[f"{prefix}scores"]).max()) if k else 0.0
-    db = float(np.abs(boxes[j, :k] - gold[f"{prefix}boxes"]).max()) if k else 0.0
+        assert np.array_equal(cls[j, :k], gold[f"{prefix}cls"][perm]), f"{prefix}: classes differ"
+    ds = float(np.abs(scores[j, :k] - g_sc[perm]).max()) if k else 0.0
+    db = float(np.abs(boxes[j, :k] - gold[f"{prefix}boxes"][perm]).max()) if k else 0.0
     assert ds <= EXACT_SCORE_EPS and db <= EXACT_BOX_EPS * scale_px, f"{prefix}: scores off by {ds}, boxes by {db} px"
-    return k, ds, db
+    return k, ties, ds, db
 
 
 @pytest.mark.parametrize("scale,frames", [("n", [(3, 40), (2, 50), (4, 0)]), ("l", [(3, 40), (2, 50)])])
@@ -349,7 +368,7 @@ def test_yolo_exact_plan_keepsets_equal_fp32(cuda, scale, frames):
         out = tuple(t.cpu().numpy() for t in det.detect(d_fr, conf=conf))
         for j in range(len(frames)):
             report.append((j, conf) + _assert_keepset_equals_golden(out, j, gold, f"f{j}_c{int(conf * 100)}_", conf, 3.0))
-    print(f"yolov8{scale} exact plan (frame, conf, kept = fp32 kept, max score diff, max box diff px):", report)
+    print(f"yolov8{scale} exact plan (frame, conf, kept = fp32 kept, detections in an fp32 score tie, max score diff, max box diff px):", report)
     # the plan is batch-independent and reproducible like the f16 one
     alone = det.forward_letterboxed(img[1:2]).cpu().numpy()
     assert np.array_equal(alone[0], pred[1]), "exact plan: frame alone differs from the frame inside the batch"
@@ -379,7 +398,7 @@ def test_cfg2_exact_plan_golden_frames(cuda):
         out = tuple(t.cpu().numpy() for t in det.detect(d_fr, conf=conf))
         for j in range(2):
             report.append((j, conf) + _assert_keepset_equals_golden(out, j, g, f"f{j}_c{int(conf * 100)}_", conf))
-    print("cfg2 exact plan (frame, conf, kept = fp32 kept, max score diff, max box diff px):", report)
+    print("cfg2 exact plan (frame, conf, kept = fp32 kept, detections in an fp32 score tie, max score diff, max box diff px):", report)
 
 
 def test_pose_exact_plan_equals_fp32(cuda):
@@ -395,7 +414,8 @@ def test_pose_exact_plan_equals_fp32(cuda):
     fr = np.stack([synth.synth_frame(int(cs), int(fi)) for cs, fi in gold["frames"]], 0)
     boxes, scores, cls, src, counts, kpts = (t.cpu().numpy() for t in det.detect_pose(torch.from_numpy(fr).to(cuda), conf=conf))
     for j in range(fr.shape[0]):
-        k, ds, db = _assert_keepset_equals_golden((boxes, scores, cls, src, counts), j, gold, f"f{j}_", conf, 3.0)
+        k, ties, ds, db = _assert_keepset_equals_golden((boxes, scores, cls, src, counts), j, gold, f"f{j}_", conf, 3.0)
+        assert ties == 0
         dk = float(np.abs(kpts[j, :k, :, :2] - gold[f"f{j}_keypoints"][..., :2]).max())
         dv = float(np.abs(kpts[j, :k, :, 2] - gold[f"f{j}_keypoints"][..., 2]).max())
         print(f"pose exact frame {j}: {k} detections = fp32, scores {ds:.1e}, boxes {db:.1e} px, keypoints {dk:.1e} px, visibility {dv:.1e}")

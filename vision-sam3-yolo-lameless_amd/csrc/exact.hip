@@ -38,6 +38,7 @@ __device__ __forceinline__ float join_hi_lo(half_t hi, half_t lo) { return (floa
 __device__ __forceinline__ float act_exact(float v, int act) {
   if (act == LMX_ACT_SILU) return v / (1.0f + expf(-v));
   if (act == LMX_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == LMX_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // the erf form torch's GELU evaluates
   return v;
 }
 
@@ -179,7 +180,167 @@ __global__ __launch_bounds__(256) void stem_conv_x3_kernel(const uint8_t* __rest
   }
 }
 
+// ---- the exact plan of the SAM mask decoder (lmx/sam_decoder.py precision="exact"): its attentions are tiny (7 tokens against 4096
+// image positions, head dims 16 / 32) and run in plain f32 on the VALU; TF:models/sam/modeling_sam.py:205-268 SamAttention.
+// Tk > 16: one wave per (batch, head, query): lanes stride over the keys, two passes (maximum, then exp / sum / weighted V:
+// the dot product is recomputed instead of stored), wave reductions at the end.
+// Tk <= 16: one thread per (batch, head, query).
+template <int HD>
+__global__ __launch_bounds__(256) void attn_f32_wave_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
+                                                            int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                                            float* __restrict__ O, int64_t ldo, int B, int H, int Tq, int Tk, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (int64_t)B * H * Tq) return;
+  const int tq = (int)(item % Tq);
+  const int64_t bh = item / Tq;
+  const int h = (int)(bh % H), b = (int)(bh / H);
+  float q[HD];
+  const float* qp = Q + ((int64_t)b * Tq + tq) * ldq + h * HD;
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(qp + d);
+    q[d] = v[0], q[d + 1] = v[1], q[d + 2] = v[2], q[d + 3] = v[3];
+  }
+  const float* Kb = K + (int64_t)b * Tk * ldk + h * HD;
+  const float* Vb = V + (int64_t)b * Tk * ldv + h * HD;
+  auto score = [&](int j) {
+    const float* kp = Kb + (int64_t)j * ldk;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(kp + d);
+      s += q[d] * v[0] + q[d + 1] * v[1] + q[d + 2] * v[2] + q[d + 3] * v[3];
+    }
+    return s * scale;
+  };
+  float mx = -INFINITY;
+  for (int j = lane; j < Tk; j += 64) mx = fmaxf(mx, score(j));
+  mx = wave_max(mx);
+  float l = 0.f, o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  for (int j = lane; j < Tk; j += 64) {
+    const float e = expf(score(j) - mx);
+    l += e;
+    const float* vp = Vb + (int64_t)j * ldv;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(vp + d);
+      o[d] += e * v[0], o[d + 1] += e * v[1], o[d + 2] += e * v[2], o[d + 3] += e * v[3];
+    }
+  }
+  l = wave_sum(l);
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = wave_sum(o[d]);
+  if (lane == 0) {
+    float* op = O + ((int64_t)b * Tq + tq) * ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = o[d] / l;
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_f32_thread_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
+                                                              int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                                              float* __restrict__ O, int64_t ldo, int B, int H, int Tq, int Tk, float scale) {
+  const int64_t total = (int64_t)B * H * Tq;
+  for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (int64_t)gridDim.x * blockDim.x) {
+    const int h = (int)(item % H);  // heads fastest: the 8 heads of a query read one contiguous row
+    const int64_t bq = item / H;
+    const int tq = (int)(bq % Tq), b = (int)(bq / Tq);
+    float q[HD];
+    const float* qp = Q + ((int64_t)b * Tq + tq) * ldq + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) q[d] = qp[d];
+    float s[16];
+    float mx = -INFINITY;
+    for (int j = 0; j < Tk; ++j) {
+      const float* kp = K + ((int64_t)b * Tk + j) * ldk + h * HD;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) a += q[d] * kp[d];
+      s[j] = a * scale;
+      mx = fmaxf(mx, s[j]);
+    }
+    float l = 0.f, o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    for (int j = 0; j < Tk; ++j) {
+      const float e = expf(s[j] - mx);
+      l += e;
+      const float* vp = V + ((int64_t)b * Tk + j) * ldv + h * HD;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] += e * vp[d];
+    }
+    float* op = O + ((int64_t)b * Tq + tq) * ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = o[d] / l;
+  }
+}
+
+// lmx_k_hyper_mask on an f32 upscaled embedding, with the upscaler's last GELU applied on load (exact erf form)
+__global__ __launch_bounds__(256) void hyper_mask_f32_kernel(const float* __restrict__ up, const float* __restrict__ hyper,
+                                                             float* __restrict__ logits, int n, int G, int C, int act) {
+  const int64_t total = (int64_t)n * G * G * 16;
+  const int S = 4 * G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q2 = (int)(i & 3), q1 = (int)((i >> 2) & 3);
+    const int64_t cell = i >> 4;
+    const int x = (int)(cell % G);
+    const int64_t r = cell / G;
+    const int y = (int)(r % G);
+    const int b = (int)(r / G);
+    const float* u = up + i * C;
+    const float* hy = hyper + (int64_t)b * C;
+    float acc = 0.f;
+    for (int c = 0; c < C; c += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(u + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc += act_exact(v[e], act) * hy[c + e];
+    }
+    const int Y = 4 * y + 2 * (q1 >> 1) + (q2 >> 1), X = 4 * x + 2 * (q1 & 1) + (q2 & 1);
+    logits[((int64_t)b * S + Y) * S + X] = acc;
+  }
+}
+
 }  // namespace
+
+extern "C" int lmx_k_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o,
+                                   int64_t ldo, int B, int H, int Tq, int Tk, int hd, float scale, lmx_stream_t stream) {
+  LMX_REQUIRE(q && k && v && o, "lmx_k_attention_f32: null pointer");
+  LMX_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (hd == 16 || hd == 32), "lmx_k_attention_f32: head dim %d (16 or 32)", hd);
+  LMX_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldq >= (int64_t)H * hd && ldk >= (int64_t)H * hd && ldv >= (int64_t)H * hd &&
+                  ldo >= (int64_t)H * hd,
+              "lmx_k_attention_f32: strides");
+  LMX_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v), "lmx_k_attention_f32: alignment");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t items = (int64_t)B * H * Tq;
+  LMX_REQUIRE(items < (1ll << 31), "lmx_k_attention_f32: too many queries");
+  if (Tk <= 16) {
+    if (hd == 16)
+      hipLaunchKernelGGL((attn_f32_thread_kernel<16>), dim3(grid_for(items)), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Tq, Tk, scale);
+    else
+      hipLaunchKernelGGL((attn_f32_thread_kernel<32>), dim3(grid_for(items)), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Tq, Tk, scale);
+    return lmx_launch_check("attn_f32_thread_kernel");
+  }
+  const unsigned grid = (unsigned)((items + 3) / 4);
+  if (hd == 16)
+    hipLaunchKernelGGL((attn_f32_wave_kernel<16>), dim3(grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Tq, Tk, scale);
+  else
+    hipLaunchKernelGGL((attn_f32_wave_kernel<32>), dim3(grid), dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Tq, Tk, scale);
+  return lmx_launch_check("attn_f32_wave_kernel");
+}
+
+extern "C" int lmx_k_hyper_mask_f32(const float* up, const float* hyper, float* logits, int n, int G, int C, int act,
+                                    lmx_stream_t stream) {
+  LMX_REQUIRE(up && hyper && logits, "lmx_k_hyper_mask_f32: null pointer");
+  LMX_REQUIRE(n > 0 && G > 0 && C > 0 && C % 4 == 0 && C <= 64 && aligned16(up), "lmx_k_hyper_mask_f32: shape");
+  LMX_REQUIRE(act == LMX_ACT_NONE || act == LMX_ACT_GELU, "lmx_k_hyper_mask_f32: activation %d", act);
+  hipLaunchKernelGGL(hyper_mask_f32_kernel, dim3(grid_for((int64_t)n * G * G * 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     up, hyper, logits, n, G, C, act);
+  return lmx_launch_check("hyper_mask_f32_kernel");
+}
 
 extern "C" int lmx_k_split3(const float* x, int64_t ldx, int act, const void* res3, int64_t ldr, void* out3, int64_t ldo,
                             int64_t rows, int N, int g, lmx_stream_t stream) {
@@ -188,7 +349,7 @@ extern "C" int lmx_k_split3(const float* x, int64_t ldx, int act, const void* re
   LMX_REQUIRE(ldx % 4 == 0 && ldx >= N && ldo % 8 == 0 && ldo >= 3 * (int64_t)N, "lmx_k_split3: strides (ldx %lld, ldo %lld)",
               (long long)ldx, (long long)ldo);
   LMX_REQUIRE(aligned16(x) && aligned16(out3), "lmx_k_split3: alignment");
-  LMX_REQUIRE(act == LMX_ACT_NONE || act == LMX_ACT_SILU || act == LMX_ACT_RELU, "lmx_k_split3: activation %d", act);
+  LMX_REQUIRE(act >= LMX_ACT_NONE && act <= LMX_ACT_RELU, "lmx_k_split3: activation %d", act);
   if (res3) LMX_REQUIRE(ldr % 8 == 0 && ldr >= 3 * (int64_t)N && aligned16(res3), "lmx_k_split3: residual stride / alignment");
   hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (N / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, act,
                      reinterpret_cast<const half_t*>(res3), ldr, reinterpret_cast<half_t*>(out3), ldo, rows, N, g);

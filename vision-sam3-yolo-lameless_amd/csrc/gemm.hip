@@ -271,7 +271,7 @@ extern "C" int lmx_k_gemm(const lmx_gemm_desc* dp, lmx_stream_t stream) {
   if (d.res) LMX_REQUIRE(d.ldr % 4 == 0 && d.ldr >= d.N, "lmx_k_gemm: bad ldr=%lld", (long long)d.ldr);
   LMX_REQUIRE(d.res_rows >= 0, "lmx_k_gemm: res_rows");
   if (d.a_mode == 0) {
-    LMX_REQUIRE(d.lda >= d.K, "lmx_k_gemm: lda=%lld < K=%d", (long long)d.lda, d.K);
+    LMX_REQUIRE(d.a_rep > 1 || d.lda >= d.K, "lmx_k_gemm: lda=%lld < K=%d", (long long)d.lda, d.K);
   } else if (d.a_mode == 1) {
     LMX_REQUIRE(d.Cin > 0 && d.Cin % 8 == 0, "lmx_k_gemm: conv Cin=%d must be a multiple of 8", d.Cin);
     LMX_REQUIRE(d.K == 9 * d.Cin, "lmx_k_gemm: conv K=%d != 9*Cin=%d", d.K, 9 * d.Cin);
@@ -292,6 +292,14 @@ extern "C" int lmx_k_gemm(const lmx_gemm_desc* dp, lmx_stream_t stream) {
                 "lmx_k_gemm: pooled rows are built for the LDS-DMA kernel (M >= 512, N >= 96, N %% 8 == 0): use GEMM + maxpool2 for M=%d N=%d", d.M, d.N);
   } else {
     LMX_REQUIRE(false, "lmx_k_gemm: bad a_mode %d", d.a_mode);
+  }
+  LMX_REQUIRE(d.a_rep >= 0 && d.a_rep <= 3, "lmx_k_gemm: a_rep=%d (0..3)", d.a_rep);
+  if (d.a_rep > 1) {
+    LMX_REQUIRE(d.a_mode == 0 && d.K % d.a_rep == 0 && (d.K / d.a_rep) % 64 == 0, "lmx_k_gemm: a_rep=%d needs a_mode 0 and K / a_rep a multiple of 64 (K=%d)", d.a_rep, d.K);
+    LMX_REQUIRE(d.lda >= d.K / d.a_rep, "lmx_k_gemm: lda=%lld < K / a_rep", (long long)d.lda);
+    LMX_REQUIRE(d.M >= 512 && d.N >= 96 && d.N % 8 == 0 && d.ldc % 8 == 0 && (!d.res || d.ldr % 8 == 0) && aligned16(d.C) && (!d.res || aligned16(d.res)),
+                "lmx_k_gemm: a_rep is built into the LDS-DMA kernel only (M >= 512, N >= 96, N %% 8 == 0); M=%d N=%d", d.M, d.N);
+    return lmx_gemm2_launch(d, reinterpret_cast<hipStream_t>(stream));
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // large dense problems take the LDS-DMA 256x128 kernel (gemm2.hip); small / narrow ones and the conv generator stay here

@@ -94,8 +94,10 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   const char* Ab = reinterpret_cast<const char*>(p.A) +
                    ((AMODE == 1) ? (int64_t)img0 * p.H * p.W_ * p.lda * 2 : (AMODE == 2 ? (int64_t)0 : (int64_t)m0 * p.lda * 2));
   const char* Wb = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.K * 2;
+  // (a_rep > 1, a_mode 0: A's own K range is K / a_rep columns, walked a_rep times — lmx.h)
+  const int Ka = (AMODE == 0 && p.a_rep > 1) ? p.K / p.a_rep : p.K;
   int64_t a_bytes = (AMODE == 1) ? ((int64_t)(p.M / hw_out - img0) * p.H * p.W_ - 1) * p.lda * 2 + (int64_t)p.Cin * 2
-                                 : ((int64_t)(p.M - (AMODE == 2 ? 0 : m0) - 1) * p.lda + p.K) * 2;
+                                 : ((int64_t)(p.M - (AMODE == 2 ? 0 : m0) - 1) * p.lda + Ka) * 2;
   int64_t w_bytes = (int64_t)(p.N - n0) * p.K * 2;
   if (a_bytes > 0x7FFFFFF0ll) a_bytes = 0x7FFFFFF0ll;
   if (w_bytes > 0x7FFFFFF0ll) w_bytes = 0x7FFFFFF0ll;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
     w_off[j] = (unsigned)(((wave * W_INSTR + j) * ROWS_PER_INSTR + lrow) * p.K * 2 + lchunk * 16);
   const unsigned OOB = 0x80000000u;
   const int nk = (p.K + BK - 1) / BK;
+  const int nkA = (AMODE == 0 && p.a_rep > 1) ? nk / p.a_rep : nk;  // k-tiles of A's own K range (Ka % 64 == 0 then: no tail)
   const bool k_tail_lane = (nk - 1) * BK + lchunk * 8 >= p.K;  // this lane's chunk is past K in the last k-tile
 
   auto issue = [&](int kt, int slot) {
@@ -146,10 +149,13 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
     const bool kill = (kt == nk - 1) && k_tail_lane;
     const int soff = kt * (BK * 2);
     if (AMODE != 1) {
+      // A columns of k-tile kt: kt mod nkA, as two scalar compare-subtracts (a_rep <= 3; nkA == nk without repetition)
+      const int kta = kt - (kt >= nkA ? nkA : 0) - (kt >= 2 * nkA ? nkA : 0);
+      const int soff_a = (AMODE == 0) ? kta * (BK * 2) : soff;
 #pragma unroll
       for (int j = 0; j < A_INSTR; ++j) {
         char* dst = st + (wave * A_INSTR + j) * 1024;
-        lds_dma16(a_rs, dst, kill ? OOB : a_off[j], soff);
+        lds_dma16(a_rs, dst, kill ? OOB : a_off[j], soff_a);
       }
     } else {
       const int k0 = kt * BK;          // wave-uniform: the whole k-tile sits in one filter tap

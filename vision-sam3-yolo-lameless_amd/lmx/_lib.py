@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("act", C.c_int32), ("out_dtype", C.c_int32), ("a_mode", C.c_int32),
         ("H", C.c_int32), ("W_", C.c_int32), ("Cin", C.c_int32), ("conv_stride", C.c_int32),
-        ("Ho", C.c_int32), ("Wo", C.c_int32), ("res_rows", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("res_rows", C.c_int32), ("a_rep", C.c_int32),
     ]
 
 
@@ -65,6 +65,8 @@ SIGNATURES = {
     "lmx_k_split3": (_I, [_VP, _I64, _I, _VP, _I64, _VP, _I64, _I64, _I, _I, _VP]),
     "lmx_k_maxpool5_x3": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
     "lmx_k_stem_conv_x3": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "lmx_k_attention_f32": (_I, [_VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _I, _I, _I, _I, _I, _F, _VP]),
+    "lmx_k_hyper_mask_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "lmx_k_maxpool5": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
     "lmx_k_upsample2": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
     "lmx_k_detect_decode": (_I, [_VP, _I64, _VP, _I, _I, _I, _I, _F, _I, _I, _VP]),

@@ -58,8 +58,10 @@ def pooled_gemm_ok(M, N):
     return M >= 512 and N >= 96 and N % 8 == 0
 
 
-def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtype=torch.float16, res_rows=0, pool_hw=None):
+def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtype=torch.float16, res_rows=0, pool_hw=None, a_rep=1):
     """out[M,N] = res + scale * act(a[M,K] @ w[N,K]^T + bias)   (lmx_k_gemm, a_mode 0).
+    a_rep > 1: w is [N, a_rep*K] and a's K columns are walked a_rep times (w = [whi | wlo]: f16 activations against 22-bit
+    weights in one launch).
     res_rows > 0: res is a [res_rows, N] table broadcast over the batch (row m uses res[m % res_rows]).
     pool_hw=(H, W): the rows of `a` are an [n, H, W] token grid and the result is the 2 x 2 max-pool of the product over that
     grid, [M/4, N] in [n, H/2, W/2] order (a_mode 2: the bits of gemm(...) followed by maxpool2, without the full-size
@@ -67,8 +69,8 @@ def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtyp
     dev = _dev(a, w, bias, scale, res, out)
     M, K, lda = _rows(a, "gemm A")
     N, K2, ldw = _rows(w, "gemm W")
-    if K2 != K or ldw != K:
-        raise LmxError(f"gemm: W must be contiguous [N,K]; A K={K}, W shape {tuple(w.shape)}")
+    if K2 != a_rep * K or ldw != K2:
+        raise LmxError(f"gemm: W must be contiguous [N,{a_rep}*K]; A K={K}, W shape {tuple(w.shape)}")
     if a.dtype != torch.float16 or w.dtype != torch.float16:
         raise LmxError("gemm: A and W must be float16")
     Mout = M // 4 if pool_hw else M
@@ -92,8 +94,8 @@ def gemm(a, w, bias=None, act=ACT_NONE, scale=None, res=None, out=None, out_dtyp
             raise LmxError("gemm: residual must match out's shape and dtype")
         d.res, d.ldr = res.data_ptr(), ldr
     d.res_rows = res_rows
-    d.M, d.N, d.K = M, N, K
-    d.act, d.out_dtype, d.a_mode = act, _DT[out.dtype], 0
+    d.M, d.N, d.K = M, N, a_rep * K
+    d.act, d.out_dtype, d.a_mode, d.a_rep = act, _DT[out.dtype], 0, a_rep
     if pool_hw:
         d.a_mode, d.H, d.W_ = 2, int(pool_hw[0]), int(pool_hw[1])
     check(_lib.load().lmx_k_gemm(C.byref(d), _stream(dev)), "lmx_k_gemm")
@@ -511,6 +513,40 @@ def add_bcast(a, b, out=None, out_dtype=torch.float32):
     return out
 
 
+def attention_f32(q, k, v, B, H, Tq, Tk, hd, scale):
+    """softmax(q k^T * scale) v in plain f32 for the SAM decoder's tiny attentions (lmx_k_attention_f32): q [B*Tq, >=H*hd],
+    k / v [B*Tk, >=H*hd] f32 row views -> f32 [B*Tq, H*hd]."""
+    dev = _dev(q, k, v)
+    for t in (q, k, v):
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise LmxError("attention_f32: q/k/v must be float32 2-D row views")
+    out = torch.empty((B * Tq, H * hd), dtype=torch.float32, device=q.device)
+    check(_lib.load().lmx_k_attention_f32(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(out), out.stride(0),
+                                          B, H, Tq, Tk, hd, float(scale), _stream(dev)), "lmx_k_attention_f32")
+    return out
+
+
+def hyper_mask_f32(up, hyper, n, G, C_, act=ACT_NONE):
+    dev = _dev(up, hyper)
+    if up.dtype != torch.float32 or not up.is_contiguous():
+        raise LmxError("hyper_mask_f32: up must be contiguous float32")
+    logits = torch.empty((n, 4 * G, 4 * G), dtype=torch.float32, device=up.device)
+    check(_lib.load().lmx_k_hyper_mask_f32(_ptr(up), _ptr(hyper), _ptr(logits), n, G, C_, act, _stream(dev)), "lmx_k_hyper_mask_f32")
+    return logits
+
+
+def split3_rows(x, act=ACT_NONE):
+    """f32 [rows, N] (row stride allowed) -> contiguous x3 rows f16 [rows, 3N] = [hi | lo | hi] (one group): the A operand of an
+    exact Linear (lmx_k_split3)."""
+    dev = _dev(x)
+    rows, N, ldx = _rows(x, "split3_rows x")
+    if x.dtype != torch.float32 or N % 8:
+        raise LmxError("split3_rows: float32 rows with N % 8 == 0 expected")
+    out = torch.empty((rows, 3 * N), dtype=torch.float16, device=x.device)
+    check(_lib.load().lmx_k_split3(_ptr(x), ldx, act, None, 0, _ptr(out), 3 * N, rows, N, N, _stream(dev)), "lmx_k_split3")
+    return out
+
+
 def prompt_box(boxes, sx, sy, S, gauss, corner):
     """boxes f32 [n,>=4] (row stride allowed) in frame pixels -> sparse f32 [n,2,2F] (lmx_k_prompt_box)."""
     dev = _dev(boxes, gauss, corner)
@@ -570,7 +606,7 @@ def _work(name, args):
         d = args[0]._obj
         M, N, Kd = d.M, d.N, d.K
         osz = 4 if d.out_dtype == F32 else 2
-        a_bytes = 2 * M * Kd
+        a_bytes = 2 * M * (Kd // max(d.a_rep, 1))
         if d.a_mode == 1:  # 3x3 implicit GEMM: the input image is read once, not 9 times
             a_bytes = 2 * (M // max(d.Ho * d.Wo, 1)) * d.H * d.W_ * d.Cin
         by = a_bytes + 2 * N * Kd + osz * (M // 4 if d.a_mode == 2 else M) * N + (osz * (d.res_rows or M) * N if d.res else 0)

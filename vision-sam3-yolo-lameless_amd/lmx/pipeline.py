@@ -65,18 +65,19 @@ class FusedExtractor:
             pool.append(torch.cuda.Stream(self.device))
         return pool[:k]
 
-    def step(self, frames, conf=0.5, sam_chunk=16, keep_byte_masks=False, det_idx=None, emb_idx=None, yolo_precision=None):
+    def step(self, frames, conf=0.5, sam_chunk=16, keep_byte_masks=False, det_idx=None, emb_idx=None, precision=None):
         """frames u8 [n,1080,1920,3] BGR on device -> dict of device tensors for every frame.  Masks are returned bit-packed
         ([n, h, ceil(w/8)], numpy.packbits order): that is what is gathered across GPUs and copied to the host;
         `keep_byte_masks` adds the u8 [n,h,w] masks the kernels produced.
         Dense schedule (default): every frame goes through all three networks.  Reference schedule: `det_idx` / `emb_idx`
         (index lists into `frames`) name the frames YOLO + SAM resp. DINO run on (yolo main.py:74, dinov3 main.py:127); the
         outputs keep n rows, zero where a network did not run, plus `ran_det` / `ran_emb` flags.
-        yolo_precision: None = the detector's default plan ("exact": keep-sets of the fp32 path, what the services' JSON must
-        carry) or "f16" (the throughput plan; bench.py's dense step) — lmx.yolo.YoloDetector."""
+        precision: None = the models' default plans ("exact": YOLO keep-sets of the fp32 path and masks within IoU 0.9995 of it —
+        what the services' JSON must carry) or "f16" (the throughput plans; bench.py's dense step) — lmx.yolo.YoloDetector,
+        lmx.sam_decoder.MaskDecoder."""
         n = frames.shape[0]
         if det_idx is None and emb_idx is None:
-            return self._step_dense(frames, conf, sam_chunk, keep_byte_masks, yolo_precision=yolo_precision)
+            return self._step_dense(frames, conf, sam_chunk, keep_byte_masks, precision=precision)
         dev = frames.device
         di = torch.as_tensor(list(range(n)) if det_idx is None else list(det_idx), dtype=torch.int64, device=dev)
         ei = torch.as_tensor(list(range(n)) if emb_idx is None else list(emb_idx), dtype=torch.int64, device=dev)
@@ -90,7 +91,7 @@ class FusedExtractor:
                    ran_det=torch.zeros((n,), dtype=torch.int32, device=dev), ran_emb=torch.zeros((n,), dtype=torch.int32, device=dev))
         fd = frames if det_idx is None else frames.index_select(0, di)
         fe = frames if emb_idx is None else frames.index_select(0, ei)
-        part = self._step_dense(fd, conf, sam_chunk, keep_byte_masks, emb_frames=fe, yolo_precision=yolo_precision)
+        part = self._step_dense(fd, conf, sam_chunk, keep_byte_masks, emb_frames=fe, precision=precision)
         if di.numel():
             for k in ("boxes", "scores", "cls", "counts", "mask_bits", "mask_stats", "mask_contour", "mask_iou"):
                 out[k].index_copy_(0, di, part[k].to(out[k].dtype))
@@ -103,7 +104,7 @@ class FusedExtractor:
             out["ran_emb"].index_fill_(0, ei, 1)
         return out
 
-    def _step_dense(self, frames, conf, sam_chunk, keep_byte_masks, emb_frames=None, yolo_precision=None):
+    def _step_dense(self, frames, conf, sam_chunk, keep_byte_masks, emb_frames=None, precision=None):
         """YOLO -> top-1 box -> SAM on every frame of `frames`; DINO on every frame of `emb_frames` (default: the same)."""
         n, h, w, _ = frames.shape
         emb_frames = frames if emb_frames is None else emb_frames
@@ -129,7 +130,7 @@ class FusedExtractor:
                 boxes, scores, cls, counts = (z((0, 300, 4), device=self.device), z((0, 300), device=self.device),
                                               z((0, 300), dtype=torch.int32, device=self.device), z((0,), dtype=torch.int32, device=self.device))
             else:
-                boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf, precision=yolo_precision)
+                boxes, scores, cls, src, counts = self.yolo.detect(frames, conf=conf, precision=precision)
             det_done = torch.cuda.Event()
             det_done.record(det_stream)
         with torch.cuda.stream(emb_stream):
@@ -138,12 +139,12 @@ class FusedExtractor:
         masks, stats, ious, conts = [], [], [], []
         for i, st in zip(chunks, sam_streams):  # Hiera activations are ~100 MB/frame: a chunk bounds the live set
             with torch.cuda.stream(st):
-                enc = self.sam.encode(frames[i:i + sam_chunk])
+                enc = self.sam.encode(frames[i:i + sam_chunk], precision=precision)
                 e2 = enc["fpn"][2]
                 st.wait_event(det_done)  # the decoder needs the boxes
                 # the service prompts SAM with the first (highest-confidence) detection of the frame (sam3 main.py:199-206);
                 # frames without a detection are decoded against an all-zero box and flagged by counts == 0
-                d = self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes[i:i + sam_chunk, 0, :], (h, w), rhw)
+                d = self.decoder.predict(e2.view(-1, e2.shape[-1]), boxes[i:i + sam_chunk, 0, :], (h, w), rhw, precision=precision)
                 # the contour part of extract_segmentation_features (sam3 main.py:118-135) on the device, on the pass's stream
                 conts.append(K.contour_features(d["mask"]))
             masks.append(d["mask"])

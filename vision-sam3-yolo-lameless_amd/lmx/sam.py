@@ -281,7 +281,9 @@ class HieraEncoder:
         stages, stages16 = self.trunk(patches, n)
         return dict(fpn=self.fpn(stages, stages16), stages=stages)
 
-    def encode(self, frames):
+    def encode(self, frames, precision=None):
+        """(precision is accepted for interface parity with SamVitEncoder and ignored: the Hiera trunk has one plan, f16
+        operands, which meets north_star's mask bar with margin — 0.9996 raw-frame IoU with the exact decoder.)"""
         img, patches = self.preprocess(frames)
         out = self.encode_patches(patches, frames.shape[0])
         out["resized"] = img
@@ -359,20 +361,30 @@ class SamVitEncoder:
     attention with decomposed relative-position bias, MLP, neck (1x1 -> LN2d -> 3x3 -> LN2d).  ``encode(frames)`` ->
     dict(fpn=[None, None, embedding f16 [n,64,64,256]], resized=...) — same shape contract as HieraEncoder for the decoder."""
 
-    def __init__(self, cfg, state_dict, device="cuda"):
+    def __init__(self, cfg, state_dict, device="cuda", precision="exact"):
+        """precision: the default plan of encode() — "exact" (services, adapters: every weight as the two-term f16 split
+        [whi | wlo], one launch per Linear with lmx_k_gemm's a_rep = 2; f16 weights alone carry 3.9e-4 of the path's 9e-4
+        relative logit error, profiles/r03_sam_vit_precision_probe.txt) or "f16" (throughput: 2x less MFMA work)."""
+        if precision not in ("exact", "f16"):
+            raise ValueError(f"precision {precision!r}: expected 'exact' or 'f16'")
+        self.precision = precision
         self.cfg = cfg
         self.device = torch.device(device)
         dev = self.device
         sd = state_dict
         D, P = cfg.hidden, cfg.patch
+        self._w32, self._w2 = {}, {}  # f32 [N, K] weights by key, and their [whi | wlo] f16 [N, 2K] form (built on first exact use)
 
         def t32(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
 
-        def t16(a):
+        def t16(a, key=None):
+            if key is not None:
+                self._w32[key] = np.ascontiguousarray(a, dtype=np.float32)
             return t32(a).to(torch.float16).contiguous()
 
         w = np.transpose(sd["vision_encoder.patch_embed.projection.weight"], (0, 2, 3, 1)).reshape(D, P * P * 3)
+        self._w32["pe"] = np.ascontiguousarray(w, dtype=np.float32)
         self.k_pad = P * P * 3  # 768: already a multiple of 8
         self.pe_w, self.pe_b = t16(w), t32(sd["vision_encoder.patch_embed.projection.bias"])
         self.pos = t32(sd["vision_encoder.pos_embed"].reshape(cfg.grid * cfg.grid, D))
@@ -383,16 +395,16 @@ class SamVitEncoder:
             self.layers.append(dict(
                 glob=i in cfg.global_idx,
                 g1=t32(sd[p + "layer_norm1.weight"]), b1=t32(sd[p + "layer_norm1.bias"]),
-                wqkv=t16(sd[p + "attn.qkv.weight"]), bqkv=t32(qb), padkv=t16(qb),
+                wqkv=t16(sd[p + "attn.qkv.weight"], f"{i}.qkv"), bqkv=t32(qb), padkv=t16(qb),
                 rh=t32(sd[p + "attn.rel_pos_h"]), rw=t32(sd[p + "attn.rel_pos_w"]),
-                wo=t16(sd[p + "attn.proj.weight"]), bo=t32(sd[p + "attn.proj.bias"]),
+                wo=t16(sd[p + "attn.proj.weight"], f"{i}.proj"), bo=t32(sd[p + "attn.proj.bias"]),
                 g2=t32(sd[p + "layer_norm2.weight"]), b2=t32(sd[p + "layer_norm2.bias"]),
-                w1=t16(sd[p + "mlp.lin1.weight"]), bb1=t32(sd[p + "mlp.lin1.bias"]),
-                w2=t16(sd[p + "mlp.lin2.weight"]), bb2=t32(sd[p + "mlp.lin2.bias"])))
-        self.n1_w = t16(sd["vision_encoder.neck.conv1.weight"][:, :, 0, 0])
+                w1=t16(sd[p + "mlp.lin1.weight"], f"{i}.fc1"), bb1=t32(sd[p + "mlp.lin1.bias"]),
+                w2=t16(sd[p + "mlp.lin2.weight"], f"{i}.fc2"), bb2=t32(sd[p + "mlp.lin2.bias"])))
+        self.n1_w = t16(sd["vision_encoder.neck.conv1.weight"][:, :, 0, 0], "n1")
         self.n1_ln = (t32(sd["vision_encoder.neck.layer_norm1.weight"]), t32(sd["vision_encoder.neck.layer_norm1.bias"]))
         c2 = sd["vision_encoder.neck.conv2.weight"]
-        self.n2_w = t16(np.transpose(c2, (0, 2, 3, 1)).reshape(c2.shape[0], -1))
+        self.n2_w = t16(np.transpose(c2, (0, 2, 3, 1)).reshape(c2.shape[0], -1), "n2")
         self.n2_ln = (t32(sd["vision_encoder.neck.layer_norm2.weight"]), t32(sd["vision_encoder.neck.layer_norm2.bias"]))
         self.lut = t32(sam_norm_lut())
         self._tabs = {}
@@ -406,15 +418,40 @@ class SamVitEncoder:
         S, P = self.cfg.image, self.cfg.patch
         return img, K.im2col_u8(img, self.lut, S, S, P, P, P, 0, self.k_pad)
 
-    def embed(self, patches, n):
+    def _split2(self, key):
+        """[whi | wlo] f16 [N, 2K] of the f32 weight `key`: whi = f16(w), wlo = f16(w - whi) (often subnormal: the f16 MFMA honours
+        subnormal operands on gfx950, tools/mfma_denorm_probe.py) — w to 2^-22 relative, or 3e-8 absolute for tiny weights."""
+        if key not in self._w2:
+            w = self._w32[key]
+            hi = w.astype(np.float16)
+            lo = (w - hi.astype(np.float32)).astype(np.float16)
+            self._w2[key] = torch.from_numpy(np.ascontiguousarray(np.concatenate([hi, lo], 1))).to(self.device)
+        return self._w2[key]
+
+    def embed(self, patches, n, precision=None):
         cfg = self.cfg
+        precision = precision or self.precision
+        if precision not in ("exact", "f16"):
+            raise ValueError(f"precision {precision!r}: expected 'exact' or 'f16'")
+        exact = precision == "exact"
         g, D, H = cfg.grid, cfg.hidden, cfg.heads
         hd = D // H
         rows = n * g * g
-        x = K.gemm(patches, self.pe_w, bias=self.pe_b, res=self.pos, res_rows=g * g, out_dtype=torch.float32)
-        for L in self.layers:
+
+        def lin(a, w16, key, **kw):  # one launch either way: f16 weights, or a_rep = 2 over [whi | wlo]
+            if exact:
+                w2 = self._split2(key)
+                if a.shape[1] % 64 == 0 and a.shape[0] >= 512 and w2.shape[0] >= 96 and w2.shape[0] % 8 == 0:
+                    return K.gemm(a, w2, a_rep=2, **kw)
+                # shapes outside the LDS-DMA kernel (toy configurations; ViT-B / L / H never get here): the same sum over an
+                # explicit [a | a] copy
+                return K.gemm(torch.cat([a, a], 1), w2, **kw)
+            return K.gemm(a, w16, **kw)
+
+        x = lin(patches, self.pe_w, "pe", bias=self.pe_b, res=self.pos, res_rows=g * g, out_dtype=torch.float32)
+        for i, L in enumerate(self.layers):
             h = K.layernorm(x, L["g1"], L["b1"], cfg.eps)
-            qkv = K.gemm(h, L["wqkv"], bias=L["bqkv"])
+            qkv = lin(h, L["wqkv"], f"{i}.qkv", bias=L["bqkv"])
             q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             a = torch.empty((rows, D), dtype=torch.float16, device=x.device)
             if L["glob"]:
@@ -424,17 +461,27 @@ class SamVitEncoder:
                 nW = (-(-g // ws)) ** 2
                 K.attention(q, k, v, a, n * nW, H, ws * ws, ws * ws, hd, hd ** -0.5, window=dict(Gh=g, Gw=g, ws=ws, q_stride=1),
                             pad_k=L["padkv"][D:2 * D], pad_v=L["padkv"][2 * D:], rel_pos=(L["rh"], L["rw"]))
-            K.gemm(a, L["wo"], bias=L["bo"], res=x, out=x)
+            lin(a, L["wo"], f"{i}.proj", bias=L["bo"], res=x, out=x)
             h2 = K.layernorm(x, L["g2"], L["b2"], cfg.eps)
-            u = K.gemm(h2, L["w1"], bias=L["bb1"], act=K.ACT_GELU)
-            K.gemm(u, L["w2"], bias=L["bb2"], res=x, out=x)
+            u = lin(h2, L["w1"], f"{i}.fc1", bias=L["bb1"], act=K.ACT_GELU)
+            lin(u, L["w2"], f"{i}.fc2", bias=L["bb2"], res=x, out=x)
         # neck: 1x1 (no bias) -> LayerNorm2d -> 3x3 (no bias) -> LayerNorm2d
-        y = K.gemm(K.cast_f16(x), self.n1_w, out_dtype=torch.float32)
+        y = lin(K.cast_f16(x), self.n1_w, "n1", out_dtype=torch.float32)
         y = K.layernorm(y, *self.n1_ln, 1e-6)
-        y = K.conv3x3(y.view(n, g, g, cfg.out_ch), self.n2_w, bias=None, act=K.ACT_NONE)
-        y = K.layernorm(y.view(rows, cfg.out_ch), *self.n2_ln, 1e-6)
+        y4 = y.view(n, g, g, cfg.out_ch)
+        if exact:  # the 3x3 as two accumulating launches of the implicit GEMM (whi, then + wlo), f32 output, f32 embedding
+            if "n2.hi" not in self._w2:
+                w2 = self._split2("n2")
+                Kc = w2.shape[1] // 2
+                self._w2["n2.hi"], self._w2["n2.lo"] = w2[:, :Kc].contiguous(), w2[:, Kc:].contiguous()
+            acc = K.conv3x3(y4, self._w2["n2.hi"], bias=None, act=K.ACT_NONE, out_dtype=torch.float32)
+            acc = K.conv3x3(y4, self._w2["n2.lo"], bias=None, act=K.ACT_NONE, res=acc, out=acc)
+            y = K.layernorm(acc.view(rows, cfg.out_ch), *self.n2_ln, 1e-6, out_dtype=torch.float32)
+        else:
+            y = K.conv3x3(y4, self.n2_w, bias=None, act=K.ACT_NONE)
+            y = K.layernorm(y.view(rows, cfg.out_ch), *self.n2_ln, 1e-6)
         return y.view(n, g, g, cfg.out_ch)
 
-    def encode(self, frames):
+    def encode(self, frames, precision=None):
         img, patches = self.preprocess(frames)
-        return dict(fpn=[None, None, self.embed(patches, frames.shape[0])], resized=img)
+        return dict(fpn=[None, None, self.embed(patches, frames.shape[0], precision)], resized=img)

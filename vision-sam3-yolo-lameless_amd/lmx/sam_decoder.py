@@ -94,11 +94,19 @@ class MaskDecoder:
     """Device-resident SAM prompt encoder + mask decoder.  ``predict(emb, boxes, frame_hw, resized_hw)`` -> dict(mask u8
     [n,h,w], stats int64 [n,8], iou f32 [n], lowres f32 [n,256,256])."""
 
-    def __init__(self, state_dict, device="cuda", image_size=1024, grid=64):
+    def __init__(self, state_dict, device="cuda", image_size=1024, grid=64, precision="exact"):
+        """precision: the default plan of predict() — "exact" (services, adapters, the reference schedule: f32 activations,
+        22-bit GEMM operands, f32 attention; masks within IoU 0.9995 of the fp32 path) or "f16" (the dense throughput
+        schedule: f16 GEMM operands)."""
+        if precision not in ("exact", "f16"):
+            raise ValueError(f"precision {precision!r}: expected 'exact' or 'f16'")
+        self.precision = precision
         self.device = torch.device(device)
         self.S, self.G = image_size, grid
         dev = self.device
         sd = state_dict
+        self._sd = {k: np.asarray(v, np.float32) for k, v in sd.items() if k.startswith("mask_decoder.")}
+        self._wx = {}
 
         def t32(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
@@ -210,11 +218,95 @@ class MaskDecoder:
         iou = self._ffn(self.iou_head, iou_tok)[:, 0]
         return logits, iou
 
-    def predict(self, emb, boxes, frame_hw, resized_hw):
-        """emb [n*G*G,256] rows of the NHWC image embedding; boxes f32 [n,>=4] device, xyxy in FRAME pixels."""
+    # ---- exact plan: f32 activations, x3 operands (csrc/exact.hip), f32 attention ---------------------------------------
+    def _lin(self, x, name, act_in=K.ACT_NONE, act=K.ACT_NONE, res=None, w2d=None, bias=None):
+        """y = act(act_in(x) @ W^T + b) (+ res) with 22-bit operands: x f32 [rows, K] is split into x3 rows (after act_in),
+        W into [whi | whi/2048 | wlo] rows pre-scaled by powers of two (lmx.yolo.split_rows_x3), ONE lmx_k_gemm launch over
+        3K with f32 output.  act may be NONE or RELU (it commutes with the positive row scale)."""
+        from .yolo import split_rows_x3
+
+        if name not in self._wx:
+            w = self._sd[name + ".weight"] if w2d is None else w2d
+            b = self._sd[name + ".bias"] if bias is None else bias
+            x3, sc, e = split_rows_x3(w, [w.shape[1]])
+            dev = self.device
+            self._wx[name] = (torch.from_numpy(x3).to(dev), torch.from_numpy(np.ldexp(b.astype(np.float32), e).astype(np.float32)).to(dev),
+                              torch.from_numpy(sc).to(dev))
+        w3, b3, sc = self._wx[name]
+        return K.gemm(K.split3_rows(x, act_in), w3, bias=b3, act=act, scale=sc, res=res, out_dtype=torch.float32)
+
+    def _attn_exact(self, p, q_in, k_in, v_in, n, tq, tk, res):
+        q = self._lin(q_in, p + "q_proj")
+        k = self._lin(k_in, p + "k_proj")
+        v = self._lin(v_in, p + "v_proj")
+        hd = q.shape[1] // HEADS
+        a = K.attention_f32(q, k, v, n, HEADS, tq, tk, hd, hd ** -0.5)
+        return self._lin(a, p + "out_proj", res=res)
+
+    def _ffn_exact(self, p, x):
+        h = self._lin(x, p + "proj_in", act=K.ACT_RELU)
+        h = self._lin(h, p + "layers.0", act=K.ACT_RELU)
+        return self._lin(h, p + "proj_out")
+
+    def lowres_exact(self, emb, sparse):
+        """The exact plan of lowres(): same launch structure, every tensor f32 (TF:models/sam/modeling_sam.py:432-543)."""
+        n = sparse.shape[0]
+        T, P = 7, self.G * self.G
+        eps = 1e-6
+        f32 = torch.float32
+        tokens = torch.cat([self.out_tokens[None].expand(n, -1, -1), sparse], dim=1).reshape(n * T, D).contiguous()
+        keys = K.add_bcast(emb, self.no_mask)                 # image embedding + dense no-mask embedding, f32
+        queries, qpe = tokens, tokens
+        for i in range(2):
+            p = f"mask_decoder.transformer.layers.{i}."
+            L = self.layers[i]
+            if i == 0:
+                queries = self._attn_exact(p + "self_attn.", queries, queries, queries, n, T, T, None)
+            else:
+                q_ = K.add_bcast(queries, qpe, out_dtype=f32)
+                queries = self._attn_exact(p + "self_attn.", q_, q_, queries, n, T, T, queries)
+            queries = K.layernorm(queries, *L["ln1"], eps, out_dtype=f32)
+            q_ = K.add_bcast(queries, qpe, out_dtype=f32)
+            k_ = K.add_bcast(keys, self.key_pe, out_dtype=f32)
+            queries = self._attn_exact(p + "cross_attn_token_to_image.", q_, k_, keys, n, T, P, queries)
+            queries = K.layernorm(queries, *L["ln2"], eps, out_dtype=f32)
+            h = self._lin(queries, p + "mlp.lin1", act=K.ACT_RELU)
+            queries = self._lin(h, p + "mlp.lin2", res=queries)
+            queries = K.layernorm(queries, *L["ln3"], eps, out_dtype=f32)
+            q_ = K.add_bcast(queries, qpe, out_dtype=f32)
+            keys = self._attn_exact(p + "cross_attn_image_to_token.", k_, q_, queries, n, P, T, keys)
+            keys = K.layernorm(keys, *L["ln4"], eps, out_dtype=f32)
+        p = "mask_decoder.transformer."
+        q_ = K.add_bcast(queries, qpe, out_dtype=f32)
+        k_ = K.add_bcast(keys, self.key_pe, out_dtype=f32)
+        queries = self._attn_exact(p + "final_attn_token_to_image.", q_, k_, keys, n, T, P, queries)
+        queries = K.layernorm(queries, *self.ln_final, 1e-5, out_dtype=f32)
+        q3 = queries.view(n, T, D)
+        iou_tok, mask_tok = q3[:, 0].contiguous(), q3[:, 1].contiguous()
+        # upscaler: ConvTranspose2d(k2, s2) as per-pixel GEMMs (weights re-laid as in __init__), LayerNorm2d row-wise on the
+        # [.., quadrant, 64] view, exact GELUs folded into the next split / the final dot product
+        w1 = self._sd["mask_decoder.upscale_conv1.weight"]
+        w2 = self._sd["mask_decoder.upscale_conv2.weight"]
+        u = self._lin(keys, "mask_decoder.upscale_conv1", w2d=np.transpose(w1, (2, 3, 1, 0)).reshape(4 * w1.shape[1], w1.shape[0]),
+                      bias=np.tile(self._sd["mask_decoder.upscale_conv1.bias"], 4))                    # [n*P, 4*64]
+        u = K.layernorm(u.view(n * P * 4, 64), *self.up_ln, eps, out_dtype=f32)
+        u = self._lin(u, "mask_decoder.upscale_conv2", act_in=K.ACT_GELU,
+                      w2d=np.transpose(w2, (2, 3, 1, 0)).reshape(4 * w2.shape[1], w2.shape[0]),
+                      bias=np.tile(self._sd["mask_decoder.upscale_conv2.bias"], 4))                    # [n*P*4, 4*32], pre-GELU
+        hyper = self._ffn_exact("mask_decoder.output_hypernetworks_mlps.0.", mask_tok)                # f32 [n,32]
+        logits = K.hyper_mask_f32(u, hyper, n, self.G, 32, act=K.ACT_GELU)
+        iou = self._ffn_exact("mask_decoder.iou_prediction_head.", iou_tok)[:, 0]
+        return logits, iou
+
+    def predict(self, emb, boxes, frame_hw, resized_hw, precision=None):
+        """emb [n*G*G,256] rows of the NHWC image embedding; boxes f32 [n,>=4] device, xyxy in FRAME pixels.
+        precision: None = this decoder's default plan, "exact" or "f16" (constructor docstring)."""
         h, w = frame_hw
         nh, nw = resized_hw
         sparse = K.prompt_box(boxes, nw / w, nh / h, float(self.S), self.gauss, self.corner)
-        logits, iou = self.lowres(emb, sparse)
+        precision = precision or self.precision
+        if precision not in ("exact", "f16"):
+            raise ValueError(f"precision {precision!r}: expected 'exact' or 'f16'")
+        logits, iou = (self.lowres_exact if precision == "exact" else self.lowres)(emb, sparse)
         mask, stats = K.mask_post(logits, self.S, nh, nw, h, w)
         return dict(mask=mask, stats=stats, iou=iou, lowres=logits)
