@@ -37,12 +37,21 @@ def _device(masks, cuda):
     return out, cont
 
 
-def _check(masks, cuda, label):
+def _check(masks, cuda, label, oracle=False):
+    """device == host C++ bit for bit; with oracle=True (small masks: the oracle is plain Python) also device == the
+    independent restatement oracle/mask_features.py — integers (area, bounding box, step counts) exactly, the perimeter-derived
+    doubles to 1e-12 (the oracle adds its steps in another order)."""
+    from oracle import mask_features as OM
+
     dev, cont = _device(masks, cuda)
     for i, m in enumerate(masks):
         ref = _host(m)
         for k in KEYS:
             assert dev[i][k] == ref[k], f"{label}[{i}] {k}: device {dev[i][k]!r} host {ref[k]!r} (contour row {cont[i].tolist()})"
+        if oracle:
+            orc = OM.features(m)
+            for k in KEYS:
+                assert dev[i][k] == pytest.approx(orc[k], rel=1e-12, abs=1e-12), f"{label}[{i}] {k}: device {dev[i][k]!r} oracle {orc[k]!r}"
     return cont
 
 
@@ -64,7 +73,7 @@ def test_analytic_shapes_and_topologies(cuda):
     shapes.append((xx - 40) ** 2 + (yy - 30) ** 2 <= 25 ** 2)                                     # disc
     m = np.zeros((h, w), bool); m[10:20, 10:20] = True; m[10:20, 30:40] = True; shapes.append(m)  # two equal squares: first in raster order wins
     m = np.zeros((h, w), bool); m[30:40, 10:20] = True; m[10:20, 30:41] = True; shapes.append(m)  # the larger one is later in raster order
-    cont = _check(np.stack(shapes, 0), cuda, "shape")
+    cont = _check(np.stack(shapes, 0), cuda, "shape", oracle=True)
     assert cont[0].tolist() == [2 * 49 * 19, 2 * (49 + 19), 0, 20, 10, 69, 29, 1]
     assert cont[1].tolist() == [0] * 8 and cont[2].tolist() == [0, 0, 0, 7, 4, 7, 4, 1]
     assert cont[4][7] == 2 and cont[8][7] == 1
@@ -84,7 +93,19 @@ def test_random_blobs_with_salt_and_pepper(cuda, seed):
     batch = np.zeros((len(masks), hh, ww), bool)
     for i, m in enumerate(masks):
         batch[i, :m.shape[0], :m.shape[1]] = m
-    _check(batch, cuda, f"blobs seed {seed}")
+    _check(batch, cuda, f"blobs seed {seed}", oracle=True)
+
+
+def test_frozen_tie_break_and_arc_length_conventions(cuda):
+    """The hand-derived cases of tests/test_mask_features.py (equal-area tie -> first component in raster order; all-isolated
+    pixels; a pure diagonal) on the device kernel: the conventions cv2 cannot pin here are at least frozen in all three
+    implementations."""
+    import test_mask_features as TM
+
+    for m, want in TM.frozen_tie_cases():
+        dev, _ = _device(m[None], cuda)
+        for k, v in want.items():
+            assert dev[0][k] == pytest.approx(v, rel=1e-15, abs=0), (k, dev[0][k], v)
 
 
 def test_1080p_masks_in_a_batch(cuda):

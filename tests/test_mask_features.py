@@ -70,3 +70,35 @@ def test_disc_is_nearly_circular():
     m = (xx - 100) ** 2 + (yy - 90) ** 2 <= 60 ** 2
     f = _c(m)
     assert 0.85 < f["circularity"] < 1.0 and abs(f["centroid_x"] - 100) < 1e-9 and abs(f["aspect_ratio"] - 1) < 1e-9
+
+
+# ---- frozen conventions where cv2's behaviour is NOT pinned (cv2 absent; DESIGN.md section 4 "parity unpinned") --------------------
+# Hand-derived expectations, so that the chosen rules cannot drift between the host code, the device kernel and the oracle:
+#  * equal contourArea: max(contours, key=cv2.contourArea) returns the first maximal element of the list findContours returned;
+#    this restatement takes the component whose first pixel comes FIRST IN RASTER ORDER (OpenCV's list order is an
+#    implementation detail — historically the reverse scan order — so a real cv2 may pick the other one on an exact tie);
+#  * perimeter = (unit steps) + (diagonal steps) * sqrt(2) in double (cv2.arcLength sums float32 segment lengths of the
+#    CHAIN_APPROX_SIMPLE polygon: equal for axis-aligned contours, ~1e-8 relative apart on diagonal runs).
+def frozen_tie_cases():
+    a = np.zeros((40, 40), bool)
+    a[2:12, 3:8] = True      # 10 rows x 5 cols, first in raster order: contourArea = 4 * 9 = 36
+    a[20:25, 10:20] = True   # 5 rows x 10 cols: contourArea = 9 * 4 = 36  (an exact tie)
+    b = np.zeros((12, 12), bool)
+    b[3, 5] = True           # isolated pixels only: every contourArea is 0
+    b[7, 2] = True
+    b[9, 9] = True
+    c = np.zeros((12, 12), bool)
+    c[np.arange(2, 8), np.arange(3, 9)] = True  # a pure diagonal of 6 pixels: out and back = 10 diagonal steps
+    return [
+        (a, dict(mask_area=100.0, area_ratio=100 / 1600, perimeter=2.0 * (4 + 9), aspect_ratio=5 / 10,
+                 circularity=4 * math.pi * 36 / (2.0 * (4 + 9)) ** 2, centroid_x=(50 * 5 + 50 * 14.5) / 100, centroid_y=(50 * 6.5 + 50 * 22) / 100)),
+        (b, dict(mask_area=3.0, area_ratio=3 / 144, perimeter=0.0, aspect_ratio=1.0, circularity=0.0, centroid_x=16 / 3, centroid_y=19 / 3)),
+        (c, dict(mask_area=6.0, area_ratio=6 / 144, perimeter=10 * math.sqrt(2.0), aspect_ratio=1.0, circularity=0.0, centroid_x=5.5, centroid_y=4.5)),
+    ]
+
+
+def test_frozen_tie_break_and_arc_length_conventions():
+    for m, want in frozen_tie_cases():
+        for impl in (_c(m), OM.features(m)):
+            for k, v in want.items():
+                assert impl[k] == pytest.approx(v, rel=1e-15, abs=0), (k, impl[k], v)

@@ -24,6 +24,15 @@
 #include <type_traits>
 #include <stdlib.h>
 
+#ifdef LMX_DBG_TIMELINE
+// development build only (make O=obj_tl EXTRA=-DLMX_DBG_TIMELINE LIB=../lmx/liblmx_tl.so; tools/attn_spp_timeline.py): per item of
+// workgroup 0, every wave stamps s_memtime at the phase boundaries of attn_spp_kernel
+__device__ unsigned long long lmx_attn_tl[64 * 8 * 8];  // [item][wave][stamp]
+extern "C" int lmx_dbg_get_attn_timeline(void* host, int64_t bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lmx_attn_tl), bytes); }
+#define ATL(i) if (blockIdx.x == 0 && lane == 0 && tl_it < 64) lmx_attn_tl[(tl_it * 8 + wave) * 8 + (i)] = __builtin_readcyclecounter()
+#else
+#define ATL(i)
+#endif
 namespace {
 
 struct Geo {
@@ -795,6 +804,294 @@ __global__ __launch_bounds__(256, QB == 2 ? 2 : 3) void attn_sp_kernel(const lmx
   }
 }
 
+
+// ---- the same whole-sequence problem (128 < Tk <= 208, Tq <= 208, head dim <= 64) as a PERSISTENT kernel (round 3).
+// attn_sp_kernel spends ~20 us per (window, head) item and workgroup (two co-resident) against ~1 us of MFMA time and ~3 us of
+// HBM time for its 66 KB: every item pays a register-staged K/V load (two dependent rounds of global loads), a barrier, then
+// per 32-query pair a global load of Q in front of the first MFMA — latencies that two co-resident workgroups only half hide.
+// Here ONE 8-wave workgroup per CU walks a contiguous range of items:
+//   * Q, K and V of item i+1 arrive by LDS-DMA (global_load_lds_dwordx4: 64-bit per-lane addresses, so window geometry and
+//     the padding vectors need no second descriptor) into the other half of a double buffer (2 x 78 KB) while item i computes;
+//     EXEC-masked lanes leave their LDS slots alone (tools/gll_probe.hip), which keeps the constant parts of the image — V's
+//     ones column for head dim <= 56, zeros beyond the head dim and beyond Tk — written once at kernel start;
+//   * the 13 query blocks are in flight at once: 7 waves take one pair each (the eighth only issues DMAs), Q fragments come
+//     from LDS, so an item is ONE round of the pair code instead of two;
+//   * one barrier per item; a wave confirms its own DMA pieces (s_waitcnt vmcnt(0)) just before it stores O, when they have
+//     long landed, so no store latency sits in front of the barrier.
+template <bool ONES>
+__global__ __launch_bounds__(512, 1) void attn_spp_kernel(const lmx_attn_desc p, const Geo geo, const int items) {
+  constexpr int RW = 64, CPR = 8, KB = 13, ROWS = KB * 16, QB = 2, NWV = 8;
+  constexpr int TEN = ROWS * RW * 2;          // bytes of one tensor image: 26 KB
+  constexpr int BUF = 3 * TEN;                // Q | K | V
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  // (kernel-argument fields the DMA plan selects between are copied to locals: a `cond ? p.a : p.b` on the argument struct makes
+  // hipcc spill the whole struct to scratch and index it there)
+  const int hd = p.hd, H_ = p.H, Tq_ = p.Tq, Tk_ = p.Tk, mode_ = geo.mode;
+  const int64_t ldq_ = p.ldq, ldk_ = p.ldk, ldv_ = p.ldv;
+  const int ws_ = geo.ws, wsq_ = geo.wsq, Gh_ = geo.Gh, Gw_ = geo.Gw, Gqh_ = geo.Gqh, Gqw_ = geo.Gqw, nWx_ = geo.nWx, nW_ = geo.nWy * geo.nWx;
+
+  // ---- constant parts of both images: zeros everywhere, then V[:, 63] = 1 (the PV MFMA then accumulates the softmax sum)
+  {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * BUF / 16; i += 512) *reinterpret_cast<u32x4*>(smem + i * 16) = z;
+    __syncthreads();
+    if (ONES)
+      for (int i = tid; i < 2 * ROWS; i += 512) {
+        const int bsel = i / ROWS, row = i - bsel * ROWS;
+        half_t* v = reinterpret_cast<half_t*>(smem + bsel * BUF + 2 * TEN);
+        v[row * RW + ((7 ^ (row & 7)) << 3) + 7] = (half_t)1.0f;
+      }
+  }
+
+  // ---- this workgroup's items: XCD x owns a contiguous range (the heads of a window, and neighbouring windows, share its L2)
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int nwg = ((int)gridDim.x + 7 - xcd) >> 3;
+  const int iq = items >> 3, ir = items & 7;
+  const int ibase = xcd < ir ? xcd * (iq + 1) : ir * (iq + 1) + (xcd - ir) * iq;
+  const int icnt = iq + (xcd < ir ? 1 : 0);
+
+  // ---- DMA plan: tensor t (0 Q, 1 K, 2 V; compile-time in the issue code) is 26 wave-instructions of 8 rows; wave w issues
+  // j = w, w + 8, w + 16, w + 24 (< 26) of every tensor; lane L -> row 8 j + (L >> 3), physical chunk L & 7 = logical chunk ^ (row & 7).
+  // Everything that does not depend on the item is computed here, once: the byte offset of the lane's piece from the item's first
+  // token (window origin resp. b * T) and the row's window coordinates for the padding test.  Per item a piece then costs one
+  // 64-bit add (plus the padding test in the edge windows only).
+  constexpr int NJ = 4;
+  unsigned rel[3][NJ];  // byte offset from the item's origin in its tensor
+  int tyx[3][NJ];       // (valid << 30) | (d << 20) | (ty << 10) | tx
+#pragma unroll
+  for (int ten = 0; ten < 3; ++ten)
+#pragma unroll
+    for (int m = 0; m < NJ; ++m) {
+      const int j = wave + NWV * m;
+      const int row = 8 * j + (lane >> 3);
+      const int lc = (lane & 7) ^ (row & 7);
+      const int d = lc * 8;
+      const int T = ten == 0 ? Tq_ : Tk_;
+      const int wsz = ten == 0 ? wsq_ : ws_;
+      const int gw = ten == 0 ? Gqw_ : Gw_;
+      const int64_t ld = ten == 0 ? ldq_ : (ten == 1 ? ldk_ : ldv_);
+      const int ty = mode_ == 0 ? 0 : row / wsz, tx = mode_ == 0 ? row : row - ty * wsz;
+      rel[ten][m] = (unsigned)((((int64_t)(mode_ == 0 ? row : ty * gw + tx)) * ld + d) * 2);
+      tyx[ten][m] = ((j < 26 && row < T && d < hd) ? (1 << 30) : 0) | (d << 20) | (ty << 10) | tx;
+    }
+  const char* Qg = reinterpret_cast<const char*>(p.Q);
+  const char* Kg = reinterpret_cast<const char*>(p.K);
+  const char* Vg = reinterpret_cast<const char*>(p.V);
+  const char* padk = reinterpret_cast<const char*>(p.pad_k);
+  const char* padv = reinterpret_cast<const char*>(p.pad_v);
+  // this lane's two query rows (fixed over the items): window coordinates for query_row without its divisions
+  int qty[QB], qtx[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int tq = (wave * QB + qb) * 16 + fr;
+    qty[qb] = mode_ == 0 ? 0 : tq / wsq_;
+    qtx[qb] = mode_ == 0 ? tq : tq - qty[qb] * wsq_;
+  }
+
+  auto issue = [&](int item, int bsel) {
+    const int h = item % H_, b = item / H_;
+    // item-uniform: origin of the item in each tensor, and how many rows / columns of its window lie on the grid
+    int img = b, wy = 0, wx = 0;
+    if (mode_ != 0) {
+      img = b / nW_;
+      const int w = b - img * nW_;
+      wy = w / nWx_;
+      wx = w - wy * nWx_;
+    }
+    const int64_t hcol = (int64_t)h * hd * 2;
+    const char *oq, *ok, *ov;
+    int qy = 1 << 20, qx = 1 << 20, ky = 1 << 20, kx = 1 << 20;  // rows / columns available (flat: unbounded)
+    if (mode_ == 0) {
+      oq = Qg + (int64_t)b * Tq_ * ldq_ * 2 + hcol;
+      ok = Kg + (int64_t)b * Tk_ * ldk_ * 2 + hcol;
+      ov = Vg + (int64_t)b * Tk_ * ldv_ * 2 + hcol;
+    } else {
+      const int64_t q0 = ((int64_t)img * Gqh_ + wy * wsq_) * Gqw_ + wx * wsq_;
+      const int64_t k0 = ((int64_t)img * Gh_ + wy * ws_) * Gw_ + wx * ws_;
+      oq = Qg + q0 * ldq_ * 2 + hcol;
+      ok = Kg + k0 * ldk_ * 2 + hcol;
+      ov = Vg + k0 * ldv_ * 2 + hcol;
+      qy = Gqh_ - wy * wsq_, qx = Gqw_ - wx * wsq_, ky = Gh_ - wy * ws_, kx = Gw_ - wx * ws_;
+    }
+    const bool edge = qy < wsq_ || qx < wsq_ || ky < ws_ || kx < ws_;  // uniform: interior windows skip every padding test
+    char* base = smem + bsel * BUF + wave * 1024;
+#pragma unroll
+    for (int ten = 0; ten < 3; ++ten) {
+      const char* org = ten == 0 ? oq : (ten == 1 ? ok : ov);
+      const char* pv = (ten == 1 ? padk : padv) + hcol;
+#pragma unroll
+      for (int m = 0; m < NJ; ++m) {
+        if (wave + NWV * m >= 26) break;
+        const int pl = tyx[ten][m];
+        bool act = (pl >> 30) & 1;
+        const char* src = org + rel[ten][m];
+        if (edge) {
+          const int ty = (pl >> 10) & 1023, tx = pl & 1023;
+          if (ten == 0) {
+            act = act && ty < qy && tx < qx;  // a padded query: nothing to load, nothing is stored for it
+          } else if (ty >= ky || tx >= kx) {
+            src = pv + ((pl >> 20) & 1023) * 2;  // a padded key: the qkv bias (what Linear(0) yields)
+          }
+        }
+        char* dst = base + ten * TEN + m * (NWV * 1024);  // wave-uniform; lane L lands at + 16 L
+        if (act) __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src), (lds_ptr_t)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  const int q4 = fr >> 2, p4 = fr & 3;
+  const int nqb = (Tq_ + 15) / 16, npair = (nqb + QB - 1) / QB;
+  __syncthreads();  // the constant parts are in place before the first DMA lands on top of them
+  if (jx < icnt) issue(ibase + jx, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int bsel = 0;
+#ifdef LMX_DBG_TIMELINE
+  int tl_it = -1;
+#endif
+  for (int li = jx; li < icnt; li += nwg, bsel ^= 1) {
+    const int item = ibase + li;
+    const int h = item % p.H, b = item / p.H;
+#ifdef LMX_DBG_TIMELINE
+    ++tl_it;
+#endif
+    ATL(0);
+    __syncthreads();  // every wave's pieces of this item have landed; every wave is done with the previous item's image
+    ATL(1);
+    if (li + nwg < icnt) issue(item + nwg, bsel ^ 1);
+    ATL(2);
+    const half_t* Qs = reinterpret_cast<const half_t*>(smem + bsel * BUF);
+    const half_t* Ks = Qs + ROWS * RW;
+    const half_t* Vs = Ks + ROWS * RW;
+    const int pr = wave;
+    if (pr < npair) {
+      half8_t qf[QB][2];
+      int64_t qrow[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const int tq = (pr * QB + qb) * 16 + fr;
+        if (mode_ == 0) {
+          qrow[qb] = tq < Tq_ ? (int64_t)b * Tq_ + tq : -1;
+        } else {
+          const int img = b / nW_, w = b - img * nW_;
+          const int wy = w / nWx_, wx = w - wy * nWx_;
+          const int y = wy * wsq_ + qty[qb], x = wx * wsq_ + qtx[qb];
+          qrow[qb] = (tq < Tq_ && y < Gqh_ && x < Gqw_) ? ((int64_t)img * Gqh_ + y) * Gqw_ + x : -1;
+        }
+        const int lr = tq < ROWS ? tq : ROWS - 1;  // (blocks past the image read a valid row; their results are never stored)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[qb][ks] = *reinterpret_cast<const half8_t*>(&Qs[lr * RW + ((((ks << 2) + fg) ^ (lr & 7)) << 3)]);
+      }
+      f32x4 sacc[QB][KB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) sacc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff = (((ks << 2) + fg) ^ (fr & (CPR - 1))) << 3;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[(kb * 16 + fr) * RW + coff]);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qb][ks], sacc[qb][kb], 0, 0, 0);
+        }
+      }
+      ATL(3);
+      half8_t pf[QB][7];
+      float l_sum[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int kb = 8; kb < KB; ++kb)
+          if (kb * 16 + 16 > Tk_) {  // (uniform: only the block that straddles Tk, and those past it, pay for the test)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kb * 16 + fg * 4 + r >= Tk_) sacc[qb][kb][r] = -INFINITY;
+          }
+        float mx = fmaxf(fmaxf(sacc[qb][0][0], sacc[qb][0][1]), fmaxf(sacc[qb][0][2], sacc[qb][0][3]));
+#pragma unroll
+        for (int kb = 1; kb < KB; ++kb)
+          mx = fmaxf(mx, fmaxf(fmaxf(sacc[qb][kb][0], sacc[qb][kb][1]), fmaxf(sacc[qb][kb][2], sacc[qb][kb][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mb = mx * sl2;
+        float rs = 0.f;
+        const half2_t ones2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+        for (int kb = 0; kb < KB + 1; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            half2_t e = {(half_t)0.0f, (half_t)0.0f};
+            if (kb < KB) {
+              const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r], sl2, -mb));
+              const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r + 1], sl2, -mb));
+              e = half2_t{(half_t)e0, (half_t)e1};
+              if (!ONES) rs = __builtin_amdgcn_fdot2(e, ones2, rs, false);
+            }
+            pf[qb][kb >> 1][(kb & 1) * 4 + r] = e[0];
+            pf[qb][kb >> 1][(kb & 1) * 4 + r + 1] = e[1];
+          }
+        l_sum[qb] = rs;
+      }
+      ATL(4);
+      f32x4 oacc[QB][4];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const int chunk = db * 2 + (p4 >> 1);
+          const int r0 = ks * 32 + fg * 4 + q4, r1 = ks == 6 ? r0 : r0 + 16;
+          const half4_t lo = lds_tr_read(&Vs[r0 * RW + ((chunk ^ (r0 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
+          const half4_t hi = lds_tr_read(&Vs[r1 * RW + ((chunk ^ (r1 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
+          const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][ks], oacc[qb][db], 0, 0, 0);
+        }
+      }
+      // my DMA pieces of the NEXT item (issued a whole pair ago) before my stores: the wait is short and no store sits in front
+      // of the next barrier's wait
+      ATL(5);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ATL(6);
+      half_t* O = reinterpret_cast<half_t*>(p.O);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float l;
+        if (ONES) {
+          l = __shfl(oacc[qb][3][3], 48 + fr, 64);
+        } else {
+          l = l_sum[qb];
+          l += __shfl_xor(l, 16, 64);
+          l += __shfl_xor(l, 32, 64);
+        }
+        const float inv = 1.0f / l;
+        if (qrow[qb] < 0) continue;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const int d = db * 16 + fg * 4;
+          if (d >= hd) continue;
+          half4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[qb][db][r] * inv);
+          *reinterpret_cast<half4_t*>(O + qrow[qb] * p.ldo + (int64_t)h * hd + d) = o;
+        }
+      }
+      ATL(7);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ATL(7);
+    }
+  }
+}
+
 }  // namespace
 
 static int build_geo(const lmx_attn_desc& d, Geo& g);
@@ -850,8 +1147,34 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   if (!no_sp && !d.rel && d.hd <= 64 && d.Tk > 128 && d.Tk <= 208 && d.Tq > 64 && d.Tq <= 208) {  // whole sequence per workgroup
     const int64_t items = (int64_t)d.B * d.H;
     LMX_REQUIRE(items < (1ll << 31), "lmx_k_attention: grid too large");
-    static int sp_qb = 0;
+    static int sp_qb = 0, no_spp = -1;
     if (!sp_qb) sp_qb = getenv("LMX_ATTN_SP_QB") ? atoi(getenv("LMX_ATTN_SP_QB")) : 2;
+    if (no_spp < 0) no_spp = getenv("LMX_ATTN_NO_SPP") ? 1 : 0;
+    // persistent double-buffered form (one 8-wave workgroup per CU walks a range of items): window geometry needs both padding
+    // vectors (a padded key with no vector would have to be WRITTEN as zeros, which the masked DMA does not do)
+    if (!no_spp && items >= 64 && (d.mode == 0 || (d.pad_k && d.pad_v)) && d.hd % 8 == 0) {
+      constexpr int SMEM = 2 * 3 * 208 * 64 * 2;
+      static bool attr_set = false;
+      if (!attr_set) {
+        LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_spp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_spp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+      }
+      static int n_cu = 0;
+      if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        LMX_HIP(hipGetDevice(&dev));
+        LMX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      const unsigned grid = (unsigned)(items < n_cu ? items : n_cu);
+      if (d.hd <= 56)
+        hipLaunchKernelGGL((attn_spp_kernel<true>), dim3(grid), dim3(512), SMEM, st, d, g, (int)items);
+      else
+        hipLaunchKernelGGL((attn_spp_kernel<false>), dim3(grid), dim3(512), SMEM, st, d, g, (int)items);
+      return lmx_launch_check("attn_spp_kernel");
+    }
     if (d.hd <= 56 && sp_qb == 2)
       hipLaunchKernelGGL((attn_sp_kernel<2, true>), dim3((unsigned)items), dim3(256), 0, st, d, g);
     else if (d.hd <= 56)

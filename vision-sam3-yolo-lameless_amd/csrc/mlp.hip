@@ -22,7 +22,7 @@ namespace lmx_mlp {
 
 constexpr int HC = 32;   // hidden units per chunk (one MFMA k-step of the second GEMM)
 
-// D: token width (multiple of 16, <= 256).  NW waves of QB 16-token blocks: a workgroup owns NW*16*QB tokens.
+// D: token width (multiple of 16, <= 512).  NW waves of QB 16-token blocks: a workgroup owns NW*16*QB tokens.
 // Every wave issues PT LDS-DMA instructions (1 KB each) per chunk: NW*PT KB = one ring slot = [W1 chunk | W2 chunk].
 // NST: LDS ring slots (NST-1 chunks in flight).  OCC: workgroups per CU the register budget must allow.
 // INLN: the LayerNorm runs in this kernel (row statistics reduced over the four lanes of a token) instead of reading the f16
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
                                                                           const float* __restrict__ bet_n,
                                                                           half_t* __restrict__ h_n) {
   constexpr int KS = (D + 31) / 32;           // k-steps of the first GEMM
-  constexpr int DP = D <= 128 ? 128 : 256;    // halfs per LDS row of a W1 chunk (power of two: XOR swizzle stays in the row)
+  constexpr int DP = D <= 128 ? 128 : (D <= 256 ? 256 : 512);  // halfs per LDS row of a W1 chunk (power of two: XOR swizzle stays in the row)
   constexpr int DB = D / 16;                  // 16-wide output blocks
   constexpr int NCH = 4 * D / HC;             // chunks
   constexpr int W1_BYTES = HC * DP * 2;       // 8 KB | 16 KB
@@ -187,10 +187,10 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
     const int left = NCH - 1 - c;
     if (LA >= 3 && left >= 2)
       wait_vmcnt<(LA >= 3 ? 2 : 0) * PT>();
-    else if (left >= 1)
-      wait_vmcnt<PT>();
+    else if (LA >= 2 && left >= 1)
+      wait_vmcnt<(LA >= 2 ? 1 : 0) * PT>();
     else
-      wait_vmcnt<0>();
+      wait_vmcnt<0>();  // (a two-slot ring, LA = 1: only chunk c itself is outstanding here)
     __builtin_amdgcn_s_barrier();  // (also publishes b1s on the first pass)
     if (c + LA < NCH) issue(c + LA, (c + LA) % NST);
     const char* st = smem + (c % NST) * STAGE;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
 template <int D, int QB, int NW, int NST, int OCC, bool INLN>
 int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const float* bet, float eps, const half_t* w1, const float* b1,
            const half_t* w2, const float* b2, int64_t rows, half_t* x16, const float* gam_n, const float* bet_n, half_t* h_n, hipStream_t st) {
-  constexpr int DP = D <= 128 ? 128 : 256;
+  constexpr int DP = D <= 128 ? 128 : (D <= 256 ? 256 : 512);
   const size_t smem = (size_t)NST * (HC * DP * 2 + DP * 64) + 4 * D * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -351,6 +351,11 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
     split_ln = getenv("LMX_MLP_SPLIT_LN") ? 1 : 0;  // the round-1 form: a LayerNorm launch into the workspace, then the fused MLP on it
   }
   // D = 112: 4 waves x 32 tokens, 48 KB ring, three workgroups per CU.  D = 224: 8 waves x 32 tokens, 128 KB ring, one per CU.
+  // (D = 448 — Hiera-B+ stage 3 — was instantiated in round 3 as launch<448, 2, 4, 2, 1, true>: 4 waves x 32 tokens, one wave per
+  // SIMD with 224 accumulator + 112 operand registers, 2 x 64 KB ring.  Correct, and SLOWER than the unfused launches: 1.03 ms
+  // against 0.76 ms for LayerNorm + fc1 + fc2 + the next LayerNorm at 122 880 tokens (profiles/r03_fused_mlp_d448.txt): every
+  // 128-token tile streams all 3.2 MB of weights through LDS with ONE chunk in flight and nothing to hide the per-chunk waits
+  // behind at one wave per SIMD.  Not dispatched; the template still accepts the width for further work.)
   if (!split_ln) {
     if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
     if (D == 112) return launch<112, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
