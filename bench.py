@@ -35,7 +35,9 @@ PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, /opt/skills/guides/MI355X_
 PEAK_HBM_GBS = 8000.0     # HBM3E peak, same table (6.3 TB/s is what a streaming copy achieves)
 # algorithmic FLOPs per 1080p frame (SURVEY.md §8d cfg#5): YOLOv8-l @384x640 + Hiera-B+ trunk+FPN @1024^2 + DINOv3 ViT-L/16 @224^2
 GFLOP_PER_FRAME = {"yolo": 99.1, "sam": 645.0, "dino": 125.7}
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")  # rocprofv3 --pmc passes of THIS command (tools/pmc.sh)
+# rocprofv3 --pmc passes of THIS command (tools/profile_round.sh -> tools/pmc.sh), the newest committed round
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_summary.json") for r in (3, 2)) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r03_pmc_summary.json"))
 
 
 def cpu_baseline(n_frames, clip_seed):
@@ -80,7 +82,7 @@ def cpu_baseline(n_frames, clip_seed):
 
 def pmc_traffic_by_class():
     """HBM bytes per launch and kernel class from the committed rocprofv3 --pmc passes of this same command
-    (tools/pmc.sh -> tools/pmc_summary.py -> profiles/r02_pmc_summary.json; FETCH_SIZE doubled per the gfx950 correction,
+    (tools/pmc.sh -> tools/pmc_summary.py -> profiles/rNN_pmc_summary.json; FETCH_SIZE doubled per the gfx950 correction,
     + WRITE_SIZE).  Counters cannot be read inside the timed run, so this is the profiled figure; None without the file."""
     if not os.path.exists(PMC_SUMMARY):
         return {}
@@ -90,7 +92,7 @@ def pmc_traffic_by_class():
     for name, r in rows.items():
         # the counters are per KERNEL NAME, the classes per launch (arithmetic intensity): the f32-output (residual-stream)
         # GEMM instantiations stand for the HBM-bound GEMM class, the f16-output ones for the MFMA-bound class — close, not
-        # identical sets of launches (profiles/r02_pmc_summary.txt has the per-kernel rows)
+        # identical sets of launches (profiles/rNN_pmc_summary.txt has the per-kernel rows)
         if "gemm2_kernel<1" in name or "gemm_kernel" in name and ", 1>" in name:
             cls = "gemm/hbm-bound"      # f32-output (residual-stream) instantiations
         elif "gemm" in name:
@@ -206,7 +208,7 @@ def main():
     ap.add_argument("--frames", type=int, default=150, help="frames of the synthetic clip per step (5 s @ 30 fps = 150)")
     ap.add_argument("--fps", type=int, default=30)
     ap.add_argument("--sam-chunk", type=int, default=30, help="frames per SAM encoder pass (each pass runs on its own HIP stream; 150 = 5 x 30)")
-    ap.add_argument("--shard-sam-chunk", type=int, default=0, help="frames per SAM pass of a rank's block in the sharded-clip step (0: ceil(block / 2))")
+    ap.add_argument("--shard-sam-chunk", type=int, default=0, help="frames per SAM pass of a rank's block in the sharded-clip step (0: one pass up to 24 frames, else equal passes of <= 30)")
     ap.add_argument("--clip-per-gpu", action="store_true", help="N > 1: make the clip-per-GPU (weak) rate the headline instead of the sharded clip")
     ap.add_argument("--shard-clip", action="store_true", help="N > 1: sharded clip as the headline (the default; kept for explicitness)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -266,7 +268,10 @@ def main():
     shard = None
     if world > 1:
         shard = frames[lo:hi] if rank == 0 else torch.from_numpy(synth.synth_clip(100, hi - lo, start=lo)).to(dev) if hi > lo else frames[:0]
-    shard_chunk = args.shard_sam_chunk or max(1, -(-(hi - lo) // 2))
+    # SAM pass size of a rank's block: one pass up to 24 frames (measured on one MI355X, 19-frame blocks = 8 ranks: one pass
+    # 536 frames/s, two passes of 10 501, passes of 7 528, of 5 534), else equal passes of at most 30 frames
+    blk = max(1, hi - lo)
+    shard_chunk = args.shard_sam_chunk or (blk if blk <= 24 else -(-blk // -(-blk // 30)))
     pinned = {}
 
     def to_host(buf):
