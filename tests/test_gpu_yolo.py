@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # caps on the measured deviation of the f16 network from the fp32 oracle near the thresholds (synthetic random weights,
 # ~60 layers of f16 activation storage); the tests print the measured values, the margin rule uses the measured ones
-EPS_SCORE_CAP, EPS_IOU_CAP = 1e-2, 1.5e-2  # measured on MI355X: 3.0e-3 .. 6.4e-3 and 3.3e-3 .. 6.9e-3
+EPS_SCORE_CAP, EPS_IOU_CAP = 7.5e-3, 8e-3  # the f16 plan's error budget; measured on MI355X: 3.0e-3 .. 6.4e-3 and 3.3e-3 .. 6.9e-3
 
 
 def _rand(shape, seed, scale=1.0):
