@@ -946,6 +946,14 @@ __global__ __launch_bounds__(512, 1) void attn_spp_kernel(const lmx_attn_desc p,
   const int q4 = fr >> 2, p4 = fr & 3;
   const int nqb = (Tq_ + 15) / 16, npair = (nqb + QB - 1) / QB;
   __syncthreads();  // the constant parts are in place before the first DMA lands on top of them
+  // Issuing a wave's ~10 LDS-DMA pieces blocks THAT wave for ~3k cycles (a wave issues one global_load_lds per ~300 cycles: a
+  // lone producer wave needs 22k cycles for the 78 pieces of an item, profiles/r03_attn_spp.txt) but not its SIMD: the two waves
+  // of a SIMD therefore issue at DIFFERENT points of the item — waves 0 - 3 before their S phase, waves 4 - 7 after it — so that
+  // one of them computes while the other sits in the vector-memory queue.
+  const bool early = wave < NWV / 2;
+  // (the second wave of each SIMD (4 - 6) is the YOUNGER one and loses the instruction arbitration by age: softmax 3.1k cycles
+  // against 1.2k for its partner.  s_setprio 2 on it swaps the roles and leaves the item period at 16k cycles: the SIMD's issue
+  // slots are what is exhausted — ~3300 instructions per item and SIMD, of which 216 are MFMAs — not one wave's share of them.)
   if (jx < icnt) issue(ibase + jx, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int bsel = 0;
@@ -961,7 +969,8 @@ __global__ __launch_bounds__(512, 1) void attn_spp_kernel(const lmx_attn_desc p,
     ATL(0);
     __syncthreads();  // every wave's pieces of this item have landed; every wave is done with the previous item's image
     ATL(1);
-    if (li + nwg < icnt) issue(item + nwg, bsel ^ 1);
+    const bool more = li + nwg < icnt;
+    if (more && (early || wave >= npair)) issue(item + nwg, bsel ^ 1);
     ATL(2);
     const half_t* Qs = reinterpret_cast<const half_t*>(smem + bsel * BUF);
     const half_t* Ks = Qs + ROWS * RW;
@@ -990,16 +999,28 @@ __global__ __launch_bounds__(512, 1) void attn_spp_kernel(const lmx_attn_desc p,
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) sacc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // K fragments through a three-deep register ring, two reads ahead of the MFMAs that consume them: left to itself hipcc
+      // re-uses ONE fragment register and emits read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs 26 times, i.e. an LDS latency per 32
+      // cycles of matrix work (the phase measured 3.0k cycles for 0.83k of MFMA: profiles/r03_attn_spp.txt)
+      {
+        auto kread = [&](int i) {  // i = ks * KB + kb
+          const int ks = i / KB, kb = i - ks * KB;
+          return *reinterpret_cast<const half8_t*>(&Ks[(kb * 16 + fr) * RW + ((((ks << 2) + fg) ^ (fr & (CPR - 1))) << 3)]);
+        };
+        half8_t kring[3];
+        kring[0] = kread(0);
+        kring[1] = kread(1);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int coff = (((ks << 2) + fg) ^ (fr & (CPR - 1))) << 3;
+        for (int i = 0; i < 2 * KB; ++i) {
+          if (i + 2 < 2 * KB) kring[(i + 2) % 3] = kread(i + 2);
+          __builtin_amdgcn_sched_barrier(0);  // keep the read ahead: nothing moves across
+          const int ks = i / KB, kb = i - ks * KB;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[(kb * 16 + fr) * RW + coff]);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qb][ks], sacc[qb][kb], 0, 0, 0);
+          for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kring[i % 3], qf[qb][ks], sacc[qb][kb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (more && !early) issue(item + nwg, bsel ^ 1);
       ATL(3);
       half8_t pf[QB][7];
       float l_sum[QB];
@@ -1043,21 +1064,29 @@ __global__ __launch_bounds__(512, 1) void attn_spp_kernel(const lmx_attn_desc p,
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 7; ++ks) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
+      {  // V^T fragments (two transposing 8-byte reads each) through the same kind of ring
+        auto vread = [&](int i) {  // i = ks * 4 + db
+          const int ks = i >> 2, db = i & 3;
           const int chunk = db * 2 + (p4 >> 1);
           const int r0 = ks * 32 + fg * 4 + q4, r1 = ks == 6 ? r0 : r0 + 16;
           const half4_t lo = lds_tr_read(&Vs[r0 * RW + ((chunk ^ (r0 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
           const half4_t hi = lds_tr_read(&Vs[r1 * RW + ((chunk ^ (r1 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
-          const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          return half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        half8_t vring[3];
+        vring[0] = vread(0);
+        vring[1] = vread(1);
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][ks], oacc[qb][db], 0, 0, 0);
+        for (int i = 0; i < 28; ++i) {
+          if (i + 2 < 28) vring[(i + 2) % 3] = vread(i + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          const int ks = i >> 2, db = i & 3;
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vring[i % 3], pf[qb][ks], oacc[qb][db], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // my DMA pieces of the NEXT item (issued a whole pair ago) before my stores: the wait is short and no store sits in front
-      // of the next barrier's wait
+      // my DMA pieces of the NEXT item before my stores: they have long landed, and no store sits in front of the next wait
       ATL(5);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       ATL(6);
