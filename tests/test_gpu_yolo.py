@@ -338,7 +338,7 @@ def _assert_keepset_equals_golden(det_out, j, gold, prefix, conf_key, scale_px=1
     ds = float(np.abs(scores[j, :k] - g_sc[perm]).max()) if k else 0.0
     db = float(np.abs(boxes[j, :k] - gold[f"{prefix}boxes"][perm]).max()) if k else 0.0
     assert ds <= EXACT_SCORE_EPS and db <= EXACT_BOX_EPS * scale_px, f"{prefix}: scores off by {ds}, boxes by {db} px"
-    return k, ties, ds, db
+    return k, ties, ds, db, perm
 
 
 @pytest.mark.parametrize("scale,frames", [("n", [(3, 40), (2, 50), (4, 0)]), ("l", [(3, 40), (2, 50)])])
@@ -367,7 +367,7 @@ def test_yolo_exact_plan_keepsets_equal_fp32(cuda, scale, frames):
     for conf in (0.25, 0.5):
         out = tuple(t.cpu().numpy() for t in det.detect(d_fr, conf=conf))
         for j in range(len(frames)):
-            report.append((j, conf) + _assert_keepset_equals_golden(out, j, gold, f"f{j}_c{int(conf * 100)}_", conf, 3.0))
+            report.append((j, conf) + _assert_keepset_equals_golden(out, j, gold, f"f{j}_c{int(conf * 100)}_", conf, 3.0)[:4])
     print(f"yolov8{scale} exact plan (frame, conf, kept = fp32 kept, detections in an fp32 score tie, max score diff, max box diff px):", report)
     # the plan is batch-independent and reproducible like the f16 one
     alone = det.forward_letterboxed(img[1:2]).cpu().numpy()
@@ -397,7 +397,7 @@ def test_cfg2_exact_plan_golden_frames(cuda):
     for conf in (0.25, 0.5):
         out = tuple(t.cpu().numpy() for t in det.detect(d_fr, conf=conf))
         for j in range(2):
-            report.append((j, conf) + _assert_keepset_equals_golden(out, j, g, f"f{j}_c{int(conf * 100)}_", conf))
+            report.append((j, conf) + _assert_keepset_equals_golden(out, j, g, f"f{j}_c{int(conf * 100)}_", conf)[:4])
     print("cfg2 exact plan (frame, conf, kept = fp32 kept, detections in an fp32 score tie, max score diff, max box diff px):", report)
 
 
@@ -414,8 +414,9 @@ def test_pose_exact_plan_equals_fp32(cuda):
     fr = np.stack([synth.synth_frame(int(cs), int(fi)) for cs, fi in gold["frames"]], 0)
     boxes, scores, cls, src, counts, kpts = (t.cpu().numpy() for t in det.detect_pose(torch.from_numpy(fr).to(cuda), conf=conf))
     for j in range(fr.shape[0]):
-        k, ties, ds, db = _assert_keepset_equals_golden((boxes, scores, cls, src, counts), j, gold, f"f{j}_", conf, 3.0)
-        dk = float(np.abs(kpts[j, :k, :, :2] - gold[f"f{j}_keypoints"][..., :2]).max())
-        dv = float(np.abs(kpts[j, :k, :, 2] - gold[f"f{j}_keypoints"][..., 2]).max())
+        k, ties, ds, db, perm = _assert_keepset_equals_golden((boxes, scores, cls, src, counts), j, gold, f"f{j}_", conf, 3.0)
+        gk = gold[f"f{j}_keypoints"][perm]  # (the golden's rows in the device's order: differs only inside an fp32 score tie)
+        dk = float(np.abs(kpts[j, :k, :, :2] - gk[..., :2]).max())
+        dv = float(np.abs(kpts[j, :k, :, 2] - gk[..., 2]).max())
         print(f"pose exact frame {j}: {k} detections = fp32 ({ties} in an fp32 score tie), scores {ds:.1e}, boxes {db:.1e} px, keypoints {dk:.1e} px, visibility {dv:.1e}")
         assert dk <= 2e-2 and dv <= EXACT_SCORE_EPS

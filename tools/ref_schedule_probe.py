@@ -13,6 +13,7 @@ from lmx import kernels as K  # noqa: E402
 from lmx import pipeline, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+CH = int(sys.argv[2]) if len(sys.argv) > 2 else 30  # frames per SAM pass
 dev = torch.device("cuda:0")
 fx = pipeline.FusedExtractor(dev)
 frames = torch.from_numpy(synth.synth_clip(100, 150)).to(dev)
@@ -24,11 +25,11 @@ emb = [j for j, i in enumerate(sched) if i % 30 == 0]
 
 def run(k, prec):
     for _ in range(3):
-        fx.step(sf, sam_chunk=30, det_idx=det, emb_idx=emb, precision=prec)
+        fx.step(sf, sam_chunk=CH, det_idx=det, emb_idx=emb, precision=prec)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(k):
-        fx.step(sf, sam_chunk=30, det_idx=det, emb_idx=emb, precision=prec)
+        fx.step(sf, sam_chunk=CH, det_idx=det, emb_idx=emb, precision=prec)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / k * 1e3
 
@@ -39,9 +40,9 @@ for prec in ("exact", "f16"):
     fx.serial = True
     ms1 = run(n, prec)
     K.start_launch_trace()
-    fx.step(sf, sam_chunk=30, det_idx=det, emb_idx=emb, precision=prec)
+    fx.step(sf, sam_chunk=CH, det_idx=det, emb_idx=emb, precision=prec)
     tr = K.stop_launch_trace()
     nl = sum(r["launches"] for r in tr.values())
     ev = sum(r["seconds"] for r in tr.values()) * 1e3
-    print(f"reference schedule, plans {prec:5s}: {ms:6.2f} ms per clip on the step's streams, {ms1:6.2f} ms on one stream; {nl} C-ABI launches per clip, "
+    print(f"reference schedule (SAM passes of {CH}), plans {prec:5s}: {ms:6.2f} ms per clip on the step's streams, {ms1:6.2f} ms on one stream; {nl} C-ABI launches per clip, "
           f"event-timed kernel time {ev:6.2f} ms", flush=True)
