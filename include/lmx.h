@@ -80,6 +80,13 @@ typedef struct {
    * and W columns kt*BK.  With W = [whi | wlo] (a_rep 2) ONE launch accumulates a.whi + a.wlo: f16 activations against
    * 22-bit weights (the exact plan of the SAM ViT encoder, lmx/sam.py).  Ka % 64 == 0; the LDS-DMA kernel's shapes only. */
   int32_t a_rep;
+  /* split-K for long-K, few-tile problems (the exact plan's 3 x 3 convolutions at 10 frames: K = 27 Cin against a few dozen
+   * tiles on 256 CUs): split_k = S >= 2 cuts the k range into S parts, part s writes ITS partial sum to C + s * split_stride
+   * (elements).  f32 output, no activation, a_mode 0 or 1 on the LDS-DMA kernel's shapes only; bias and residual enter partial 0,
+   * `scale` applies to every partial (the epilogue is linear), and the consumer adds the S partials in a fixed order
+   * (lmx_k_split3's `nsum`): deterministic, unlike atomics.  0 / 1: no split. */
+  int32_t split_k;
+  int64_t split_stride;
 } lmx_gemm_desc;
 int lmx_k_gemm(const lmx_gemm_desc* d, lmx_stream_t stream);
 /* development hook (tools/gemm_sweep.py): force one tiling of the LDS-DMA GEMM for every following launch; v = 0 restores
@@ -242,7 +249,9 @@ int lmx_k_scale_boxes(float* boxes, int total, float padx, float pady, float gai
  * lmx_k_stem_conv_x3: lmx_k_stem_conv writing x3: out3 f16 [n][H/2][W/2][3*Cout].
  * (nearest upsampling of an x3 slice is lmx_k_upsample2 over 3C channels.) */
 int lmx_k_split3(const float* x, int64_t ldx, int act, const void* res3, int64_t ldr, void* out3, int64_t ldo, int64_t rows,
-                 int N, int g, lmx_stream_t stream);
+                 int N, int g, int nsum, int64_t sum_stride, lmx_stream_t stream);
+/* (nsum > 1: x is the sum of nsum partial tensors x + s * sum_stride (elements), s = 0 .. nsum-1 added in that order — the
+ * partial outputs of a split-K lmx_k_gemm launch) */
 int lmx_k_maxpool5_x3(const void* src3, int64_t lds, void* dst3, int64_t ldd, int n, int H, int W, int C, lmx_stream_t stream);
 int lmx_k_stem_conv_x3(const uint8_t* img, const float* w, const float* bias, void* out3, int n, int H, int W, int Cout,
                        lmx_stream_t stream);

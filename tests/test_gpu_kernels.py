@@ -438,3 +438,35 @@ def test_large_launches_are_bit_reproducible(cuda):
     r0 = Kk.gemm(a, w, act=Kk.ACT_GELU)
     for _ in range(3):
         assert torch.equal(Kk.gemm(a, w, act=Kk.ACT_GELU), r0), "GEMM differs between identical launches"
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,stride,S", [(3, 24, 40, 96, 256, 1, 4), (1, 12, 20, 192, 128, 1, 8), (2, 48, 80, 96, 128, 2, 3), (5, 24, 40, 768, 256, 1, 8), (2, 12, 20, 768, 64, 1, 8)])
+def test_conv3x3_split_k_partials(cuda, n, H, W, cin, cout, stride, S):
+    """lmx_k_gemm split_k (the exact plan's long-K 3 x 3 convolutions): the S partial outputs add up to the unsplit f32 result
+    (another summation order: ~1e-6 relative, not bit-equal), bias and scale are applied once, the parts are the same whatever
+    the batch (a frame alone gives the bits it gives inside the batch) and lmx_k_split3 adds them in index order."""
+    from lmx import kernels as K
+
+    g = torch.Generator(device=cuda).manual_seed(cin + S)
+    x = torch.randn((n, H, W, cin), device=cuda, generator=g).half()
+    w = (torch.randn((cout, 9 * cin), device=cuda, generator=g) * (9 * cin) ** -0.5).half()
+    bias = torch.randn((cout,), device=cuda, generator=g)
+    scale = torch.rand((cout,), device=cuda, generator=g) + 0.5
+    ref = K.conv3x3(x, w, bias, act=K.ACT_NONE, stride=stride, scale=scale, out_dtype=torch.float32)
+    parts = K.conv3x3(x, w, bias, act=K.ACT_NONE, stride=stride, scale=scale, out_dtype=torch.float32, split_k=S)
+    assert parts.shape[0] == S and parts.shape[1:] == ref.shape
+    tot = parts[0].clone()
+    for s in range(1, S):
+        tot += parts[s]
+    err = float((tot - ref).abs().max() / ref.abs().max())
+    assert err < 5e-6, err
+    assert float(parts[1:].abs().max()) > 0 and float((parts[0] - ref).abs().max()) > 1e-3, "the k range was not split"
+    alone = K.conv3x3(x[n - 1:n].contiguous(), w, bias, act=K.ACT_NONE, stride=stride, scale=scale, out_dtype=torch.float32, split_k=S)
+    assert torch.equal(alone[:, 0], parts[:, n - 1]), "a frame's partial sums depend on the batch"
+    out3 = torch.empty(ref.shape[:3] + (3 * cout,), dtype=torch.float16, device=cuda)
+    K.split3(parts, K.ACT_SILU, out3)
+    v = tot / (1 + torch.exp(-tot))
+    hi = out3[..., :cout].float()
+    lo = out3[..., cout:2 * cout].float() / 2048
+    assert torch.equal(out3[..., 2 * cout:], out3[..., :cout])
+    assert float((hi + lo - v).abs().max()) <= 2e-6 * float(v.abs().max()) + 1e-7

@@ -45,7 +45,8 @@ __device__ __forceinline__ float act_exact(float v, int act) {
 // rows x N f32 (row stride ldx) -> x3 groups of width g in a channel slice with pixel stride ldo (in f16 elements); an
 // optional x3 residual (same grouping, pixel stride ldr) is added after the activation (C2f's shortcut: y = x + cv2(cv1(x)))
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t ldx, int act, const half_t* __restrict__ res,
-                                                     int64_t ldr, half_t* __restrict__ out, int64_t ldo, int64_t rows, int N, int g) {
+                                                     int64_t ldr, half_t* __restrict__ out, int64_t ldo, int64_t rows, int N, int g,
+                                                     int nsum, int64_t sstride) {
   const int nc = N / 8;
   const int64_t total = rows * nc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -53,8 +54,12 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     const int64_t m = i / nc;
     const int q = n0 / g, r = n0 - q * g;
     const int base = q * 3 * g + r;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(x + m * ldx + n0);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(x + m * ldx + n0 + 4);
+    f32x4 a = *reinterpret_cast<const f32x4*>(x + m * ldx + n0);
+    f32x4 b = *reinterpret_cast<const f32x4*>(x + m * ldx + n0 + 4);
+    for (int sidx = 1; sidx < nsum; ++sidx) {  // split-K partials, added in index order
+      a += *reinterpret_cast<const f32x4*>(x + sidx * sstride + m * ldx + n0);
+      b += *reinterpret_cast<const f32x4*>(x + sidx * sstride + m * ldx + n0 + 4);
+    }
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = act_exact(v[e], act);
@@ -343,7 +348,7 @@ extern "C" int lmx_k_hyper_mask_f32(const float* up, const float* hyper, float* 
 }
 
 extern "C" int lmx_k_split3(const float* x, int64_t ldx, int act, const void* res3, int64_t ldr, void* out3, int64_t ldo,
-                            int64_t rows, int N, int g, lmx_stream_t stream) {
+                            int64_t rows, int N, int g, int nsum, int64_t sum_stride, lmx_stream_t stream) {
   LMX_REQUIRE(x && out3, "lmx_k_split3: null pointer");
   LMX_REQUIRE(rows > 0 && N > 0 && g > 0 && g % 8 == 0 && N % g == 0, "lmx_k_split3: N=%d must be whole groups of g=%d (g %% 8 == 0)", N, g);
   LMX_REQUIRE(ldx % 4 == 0 && ldx >= N && ldo % 8 == 0 && ldo >= 3 * (int64_t)N, "lmx_k_split3: strides (ldx %lld, ldo %lld)",
@@ -351,8 +356,9 @@ extern "C" int lmx_k_split3(const float* x, int64_t ldx, int act, const void* re
   LMX_REQUIRE(aligned16(x) && aligned16(out3), "lmx_k_split3: alignment");
   LMX_REQUIRE(act >= LMX_ACT_NONE && act <= LMX_ACT_RELU, "lmx_k_split3: activation %d", act);
   if (res3) LMX_REQUIRE(ldr % 8 == 0 && ldr >= 3 * (int64_t)N && aligned16(res3), "lmx_k_split3: residual stride / alignment");
+  LMX_REQUIRE(nsum >= 1 && nsum <= 64 && (nsum == 1 || sum_stride % 4 == 0), "lmx_k_split3: nsum=%d sum_stride=%lld", nsum, (long long)sum_stride);
   hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (N / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, act,
-                     reinterpret_cast<const half_t*>(res3), ldr, reinterpret_cast<half_t*>(out3), ldo, rows, N, g);
+                     reinterpret_cast<const half_t*>(res3), ldr, reinterpret_cast<half_t*>(out3), ldo, rows, N, g, nsum, sum_stride);
   return lmx_launch_check("split3_kernel");
 }
 

@@ -294,6 +294,18 @@ extern "C" int lmx_k_gemm(const lmx_gemm_desc* dp, lmx_stream_t stream) {
     LMX_REQUIRE(false, "lmx_k_gemm: bad a_mode %d", d.a_mode);
   }
   LMX_REQUIRE(d.a_rep >= 0 && d.a_rep <= 3, "lmx_k_gemm: a_rep=%d (0..3)", d.a_rep);
+  LMX_REQUIRE(d.split_k >= 0 && d.split_k <= 64, "lmx_k_gemm: split_k=%d (0..64)", d.split_k);
+  if (d.split_k > 1) {
+    LMX_REQUIRE(d.out_dtype == LMX_F32 && d.act == LMX_ACT_NONE && d.a_mode != 2 && d.a_rep <= 1, "lmx_k_gemm: split_k needs f32 output, no activation, a_mode 0 or 1");
+    LMX_REQUIRE(d.split_stride >= (int64_t)(d.M - 1) * d.ldc + d.N && d.split_stride % 4 == 0, "lmx_k_gemm: split_stride=%lld", (long long)d.split_stride);
+    LMX_REQUIRE((d.K + 63) / 64 >= d.split_k, "lmx_k_gemm: split_k=%d exceeds the k-tiles of K=%d", d.split_k, d.K);
+    const bool conv_ok2 = d.a_mode == 1 && d.Cin % 32 == 0 && d.H < 32768 && d.W_ < 32768;
+    // (any M: whether a layer is split must not depend on the batch, or a frame's bits would; the LDS-DMA kernel zero-fills short tiles)
+    LMX_REQUIRE((d.a_mode == 0 || conv_ok2) && d.N >= 64 && d.N % 8 == 0 && d.ldc % 8 == 0 && (!d.res || d.ldr % 8 == 0) &&
+                    aligned16(d.C) && (!d.res || aligned16(d.res)),
+                "lmx_k_gemm: split_k is built into the LDS-DMA kernel only (N >= 64, N %% 8 == 0; conv: Cin %% 32 == 0); M=%d N=%d", d.M, d.N);
+    return lmx_gemm2_launch(d, reinterpret_cast<hipStream_t>(stream));
+  }
   if (d.a_rep > 1) {
     LMX_REQUIRE(d.a_mode == 0 && d.K % d.a_rep == 0 && (d.K / d.a_rep) % 64 == 0, "lmx_k_gemm: a_rep=%d needs a_mode 0 and K / a_rep a multiple of 64 (K=%d)", d.a_rep, d.K);
     LMX_REQUIRE(d.lda >= d.K / d.a_rep, "lmx_k_gemm: lda=%lld < K / a_rep", (long long)d.lda);

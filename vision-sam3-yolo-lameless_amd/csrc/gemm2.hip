@@ -81,7 +81,11 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   const int NT = (p.N + BN - 1) / BN;
   for (int li = bid >> 3; li < cnt; li += stride) {
   const int swz = base + li;
-  const int mt = swz / NT, nt = swz - mt * NT;
+  // split-K (f32 output only; lmx.h): work item swz = tile * S + s computes k-tiles [s nk / S, (s + 1) nk / S) of its tile into
+  // the s-th partial output; bias and residual go into partial 0, the consumer adds the partials up in a fixed order
+  const int S_ = p.split_k > 1 ? p.split_k : 1;
+  const int tile_ = swz / S_, sp_ = swz - tile_ * S_;
+  const int mt = tile_ / NT, nt = tile_ - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
   TL(0, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));
   TL(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));
@@ -141,6 +145,11 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
     w_off[j] = (unsigned)(((wave * W_INSTR + j) * ROWS_PER_INSTR + lrow) * p.K * 2 + lchunk * 16);
   const unsigned OOB = 0x80000000u;
   const int nk = (p.K + BK - 1) / BK;
+  // this work item's k-tiles; the part boundaries are multiples of 64 columns whatever BK is, so every tiling sums the same ranges
+  const int nk64 = (p.K + 63) / 64;
+  const int kt0 = (int)((int64_t)sp_ * nk64 / S_) * (64 / BK);
+  const int kte = sp_ + 1 == S_ ? nk : (int)((int64_t)(sp_ + 1) * nk64 / S_) * (64 / BK);
+  const int nloc = kte - kt0;
   const int nkA = (AMODE == 0 && p.a_rep > 1) ? nk / p.a_rep : nk;  // k-tiles of A's own K range (Ka % 64 == 0 then: no tail)
   const bool k_tail_lane = (nk - 1) * BK + lchunk * 8 >= p.K;  // this lane's chunk is past K in the last k-tile
 
@@ -189,28 +198,28 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   // (the convolution variant has no registers to spare across its k-loop and asks after it)
   float bias_v = 0.f, scale_v = 1.f;
   if (AMODE != 1 && tid < BN && n0 + tid < p.N) {
-    if (p.bias) bias_v = p.bias[n0 + tid];
+    if (p.bias && sp_ == 0) bias_v = p.bias[n0 + tid];
     if (p.scale) scale_v = p.scale[n0 + tid];
   }
 
 #pragma unroll
   for (int t = 0; t < LA; ++t)
-    if (t < nk) issue(t, t);
+    if (t < nloc) issue(kt0 + t, t);
 
   const int frow = lane & 15, fq = lane >> 4;
   const int fsw = (BK == 64) ? (frow & 7) : ((-(frow >> 2)) & 3);
   constexpr int PT = A_INSTR + W_INSTR;
   if constexpr (STAG == 0) {
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nloc; ++kt) {  // (kt: index among this work item's k-tiles; the data is k-tile kt0 + kt)
     // tile kt has landed once only the LDS-DMAs of the (at most LA-1) younger tiles are outstanding
-    const int left = nk - 1 - kt;
+    const int left = nloc - 1 - kt;
     wait_tiles<PT>(left < LA - 1 ? left : LA - 1);
     __builtin_amdgcn_s_barrier();
 #ifdef LMX_DBG_TIMELINE
     if (kt == 0) { TL(6, wall_clock64()); }
     if (kt == 1) { TL(7, wall_clock64()); }
 #endif
-    if (kt + LA < nk) issue(kt + LA, (kt + LA) % NSTAGE);
+    if (kt + LA < nloc) issue(kt0 + kt + LA, (kt + LA) % NSTAGE);
     const char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
     const half_t* as = reinterpret_cast<const half_t*>(st) + (wm * 64 + frow) * BK;
     const half_t* ws = reinterpret_cast<const half_t*>(st + BM * BK * 2) + (wn * 64 + frow) * BK;
@@ -241,12 +250,12 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   // (group 1's X(kt-1), interval 2kt-1, drained by lgkmcnt(0) before its barrier) precede interval 2kt.
   const int grp = wave >= NWAVE / 2 ? 1 : 0;
   {
-    const int y = nk - 1 < LA - 1 ? nk - 1 : LA - 1;  // tiles 1.. may stay in flight; tile 0 must have landed
+    const int y = nloc - 1 < LA - 1 ? nloc - 1 : LA - 1;  // tiles 1.. may stay in flight; tile 0 must have landed
     wait_tiles<PT>(y);
   }
   __builtin_amdgcn_s_barrier();
   if (grp) __builtin_amdgcn_s_barrier();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nloc; ++kt) {
     const char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
     const half_t* as = reinterpret_cast<const half_t*>(st) + (wm * 64 + frow) * BK;
     const half_t* ws = reinterpret_cast<const half_t*>(st + BM * BK * 2) + (wn * 64 + frow) * BK;
@@ -259,11 +268,11 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const half8_t*>(as + i * 16 * BK + coff);
     }
-    if (kt + 1 < nk) {
-      const int rest = nk - 2 - kt;  // tiles younger than kt+1 that exist
+    if (kt + 1 < nloc) {
+      const int rest = nloc - 2 - kt;  // tiles younger than kt+1 that exist
       wait_tiles<PT>(rest < LA - 2 ? (rest < 0 ? 0 : rest) : (LA - 2 < 0 ? 0 : LA - 2));
     }
-    if (kt + LA < nk) issue(kt + LA, (kt + LA) % NSTAGE);
+    if (kt + LA < nloc) issue(kt0 + kt + LA, (kt + LA) % NSTAGE);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
   // 16-byte lane stores; the residual is read in the same coalesced shape.  bias / activation / LayerScale are applied
   // in registers on the way in.
   if (AMODE == 1 && tid < BN && n0 + tid < p.N) {
-    if (p.bias) bias_v = p.bias[n0 + tid];
+    if (p.bias && sp_ == 0) bias_v = p.bias[n0 + tid];
     if (p.scale) scale_v = p.scale[n0 + tid];
   }
   if (tid < BN) {
@@ -406,7 +415,8 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
       // profiles/r02_gemm_epilogue.txt)
       const int lrow = lane >> 4, c16 = lane & 15;
       const int n = n0 + wn * 64 + c16 * 4;
-      const bool has_res = p.res != nullptr;
+      const bool has_res = p.res != nullptr && sp_ == 0;
+      float* Cs = reinterpret_cast<float*>(p.C) + (int64_t)sp_ * p.split_stride;  // this partial's output
       f32x4 rr[4];
       auto load_res = [&](int pass) {
         f32x4* d = rr;
@@ -432,7 +442,7 @@ __global__ __launch_bounds__(waves_per_simd(BM, BN, BK, NSTAGE) * 256) void gemm
           const int m = m0 + wm * 64 + pass * 16 + row;
           if (m < p.M && n < p.N) {
             if (has_res) o += rr[it];
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = o;
+            *reinterpret_cast<f32x4*>(Cs + (int64_t)m * p.ldc + n) = o;
           }
         }
       }
@@ -471,7 +481,7 @@ int launch2(const lmx_gemm_desc& d, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
-  const int ntiles = MT * NT;
+  const int ntiles = MT * NT * (d.split_k > 1 ? d.split_k : 1);
   int grid = ntiles;
   static int persist = -1, nt_ok = 1;  // LMX_GEMM2_PERSIST = workgroups per CU of the persistent grid (0: one per tile)
   if (persist < 0) {

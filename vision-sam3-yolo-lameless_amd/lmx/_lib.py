@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("act", C.c_int32), ("out_dtype", C.c_int32), ("a_mode", C.c_int32),
         ("H", C.c_int32), ("W_", C.c_int32), ("Cin", C.c_int32), ("conv_stride", C.c_int32),
-        ("Ho", C.c_int32), ("Wo", C.c_int32), ("res_rows", C.c_int32), ("a_rep", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("res_rows", C.c_int32), ("a_rep", C.c_int32), ("split_k", C.c_int32), ("split_stride", C.c_int64),
     ]
 
 
@@ -62,7 +62,7 @@ SIGNATURES = {
     "lmx_k_nms": (_I, [_VP, _I, _I, _I, _F, _D, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "lmx_k_letterbox": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _VP]),
     "lmx_k_stem_conv": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
-    "lmx_k_split3": (_I, [_VP, _I64, _I, _VP, _I64, _VP, _I64, _I64, _I, _I, _VP]),
+    "lmx_k_split3": (_I, [_VP, _I64, _I, _VP, _I64, _VP, _I64, _I64, _I, _I, _I, _I64, _VP]),
     "lmx_k_maxpool5_x3": (_I, [_VP, _I64, _VP, _I64, _I, _I, _I, _I, _VP]),
     "lmx_k_stem_conv_x3": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "lmx_k_attention_f32": (_I, [_VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _I, _I, _I, _I, _I, _F, _VP]),

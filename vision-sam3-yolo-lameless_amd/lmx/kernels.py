@@ -147,7 +147,21 @@ def _nhwc(t, what):
     return n, H, W, Cc, ps
 
 
-def conv3x3(x, w, bias=None, act=ACT_SILU, stride=1, res=None, out=None, scale=None, out_dtype=torch.float16):
+def split_k_for(px_per_frame, N, K, cin):
+    """Split factor of an f32-output 3 x 3 convolution in the exact plan (lmx_k_gemm split_k): K = 27 Cin against a handful of
+    256 x 256 tiles per frame leaves most of the 256 CUs idle at the reference schedule's 10 frames (M = 9600, N = 256, K = 6912:
+    38 tiles, 122 us).  The factor is a function of the LAYER — pixels of ONE frame, N, K — never of the batch: the summation
+    order, and so a frame's bits, must not depend on the batch the frame rides in.  1 = no split (also outside the LDS-DMA
+    kernel's shapes)."""
+    if N < 64 or N % 8 or cin % 32:
+        return 1
+    tiles1 = -(-px_per_frame // 256) * -(-N // 256)  # tiles one frame contributes
+    nk = K // 64
+    s = min(8, nk // 8, 32 // tiles1)
+    return s if s >= 2 else 1
+
+
+def conv3x3(x, w, bias=None, act=ACT_SILU, stride=1, res=None, out=None, scale=None, out_dtype=torch.float16, split_k=1):
     """3x3 / pad 1 convolution as implicit GEMM (lmx_k_gemm, a_mode 1).  x: NHWC f16 (may be a channel slice),
     w: f16 [Cout, 9*Cin] packed (ky,kx,ci); out: NHWC f16 or f32 (may be a channel slice of a wider buffer);
     scale: f32 [Cout] applied after bias + activation (the exact plan's power-of-two row scales)."""
@@ -157,6 +171,12 @@ def conv3x3(x, w, bias=None, act=ACT_SILU, stride=1, res=None, out=None, scale=N
     if w.dim() != 2 or w.shape[1] != 9 * Cin or not w.is_contiguous():
         raise LmxError(f"conv3x3: W must be contiguous [Cout, 9*Cin={9 * Cin}], got {tuple(w.shape)}")
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    parts = None
+    if split_k > 1:  # S partial outputs [S, n, Ho, Wo, Cout] f32; the consumer (split3 nsum=S) adds them up
+        if out is not None or res is not None or act != ACT_NONE or out_dtype != torch.float32:
+            raise LmxError("conv3x3: split_k needs a fresh f32 output, no residual, no activation")
+        parts = torch.empty((split_k, n, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        out = parts[0]
     if out is None:
         out = torch.empty((n, Ho, Wo, Cout), dtype=out_dtype, device=x.device)
     no, Ho2, Wo2, Co2, pso = _nhwc(out, "conv3x3 out")
@@ -177,8 +197,10 @@ def conv3x3(x, w, bias=None, act=ACT_SILU, stride=1, res=None, out=None, scale=N
     d.M, d.N, d.K = n * Ho * Wo, Cout, 9 * Cin
     d.act, d.out_dtype, d.a_mode = act, _DT[out.dtype], 1
     d.H, d.W_, d.Cin, d.conv_stride, d.Ho, d.Wo = H, W, Cin, stride, Ho, Wo
+    if parts is not None:
+        d.split_k, d.split_stride = split_k, parts.stride(0)
     check(_lib.load().lmx_k_gemm(C.byref(d), _stream(dev)), "lmx_k_gemm(conv3x3)")
-    return out
+    return out if parts is None else parts
 
 
 def conv1x1(x, w, bias=None, act=ACT_SILU, res=None, out=None, out_dtype=torch.float16, scale=None):
@@ -421,8 +443,13 @@ def upsample2(x, out):
 # ---- the exact plan's x3 format (csrc/exact.hip): a value travels as the f16 channel triple [hi | lo | hi] per group ----------
 def split3(x, act, out3, g=None, res3=None):
     """f32 NHWC x [n,H,W,N] (channel slices allowed) -> x3 groups of width g written into out3 [n,H,W,3N] (a channel slice of
-    an x3 buffer); y = act(x) + value(res3) (lmx_k_split3)."""
+    an x3 buffer); y = act(x) + value(res3) (lmx_k_split3).  x may be the [S, n,H,W,N] partial outputs of a split-K launch:
+    they are added up in index order first."""
     dev = _dev(x, out3, res3)
+    nsum, sstride = 1, 0
+    if x.dim() == 5:
+        nsum, sstride = x.shape[0], x.stride(0)
+        x = x[0]
     n, H, W, N, ps = _nhwc(x, "split3 x")
     no, Ho, Wo, C3, pso = _nhwc(out3, "split3 out")
     g = g or N
@@ -433,7 +460,8 @@ def split3(x, act, out3, g=None, res3=None):
         nr, Hr, Wr, Cr, ldr = _nhwc(res3, "split3 res")
         if (nr, Hr, Wr, Cr) != (n, H, W, 3 * N) or res3.dtype != torch.float16:
             raise LmxError("split3: residual must be an x3 tensor of the output's shape")
-    check(_lib.load().lmx_k_split3(_ptr(x), ps, act, _ptr(res3), ldr, _ptr(out3), pso, n * H * W, N, g, _stream(dev)), "lmx_k_split3")
+    check(_lib.load().lmx_k_split3(_ptr(x), ps, act, _ptr(res3), ldr, _ptr(out3), pso, n * H * W, N, g, nsum, sstride, _stream(dev)),
+          "lmx_k_split3")
     return out3
 
 
@@ -543,7 +571,7 @@ def split3_rows(x, act=ACT_NONE):
     if x.dtype != torch.float32 or N % 8:
         raise LmxError("split3_rows: float32 rows with N % 8 == 0 expected")
     out = torch.empty((rows, 3 * N), dtype=torch.float16, device=x.device)
-    check(_lib.load().lmx_k_split3(_ptr(x), ldx, act, None, 0, _ptr(out), 3 * N, rows, N, N, _stream(dev)), "lmx_k_split3")
+    check(_lib.load().lmx_k_split3(_ptr(x), ldx, act, None, 0, _ptr(out), 3 * N, rows, N, N, 1, 0, _stream(dev)), "lmx_k_split3")
     return out
 
 

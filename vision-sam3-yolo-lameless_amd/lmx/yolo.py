@@ -294,9 +294,14 @@ class _PlanExact:
 
     def conv3(self, x, name, stride=1, res=None, out=None):
         w, b, sc = self._w(name)
-        t = K.conv3x3(x, w, b, act=K.ACT_NONE, stride=stride, scale=sc, out_dtype=torch.float32)
+        n, H, W, cin = x.shape
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        # a 3 x 3 convolution over K = 27 Cin is a handful of tiles per frame: split its k range over the idle CUs.  The factor
+        # depends on the layer only (pixels of ONE frame), so a frame's bits do not depend on the batch it rides in
+        sk = K.split_k_for(Ho * Wo, w.shape[0], w.shape[1], cin)
+        t = K.conv3x3(x, w, b, act=K.ACT_NONE, stride=stride, scale=sc, out_dtype=torch.float32, split_k=sk)
         if out is None:
-            out = torch.empty(t.shape[:3] + (3 * t.shape[3],), dtype=torch.float16, device=t.device)
+            out = torch.empty((n, Ho, Wo, 3 * w.shape[0]), dtype=torch.float16, device=x.device)
         return K.split3(t, K.ACT_SILU, out, res3=res)
 
     def conv1(self, x, name, out=None, groups=None, g_out=None):
