@@ -228,6 +228,9 @@ def _attn_ref(q, k, v, scale):
                                       # 128 < T <= 208 takes the whole-sequence kernel (attn_sp_kernel): both edges, a ragged
                                       # last 16-key block, an odd number of 16-query blocks, head-dim padding, ones-column / dot2 sums
                                       (2, 8, 196, 56), (1, 3, 208, 64), (2, 2, 129, 32), (3, 5, 150, 48), (1, 2, 193, 64), (2, 1, 209, 56),
+                                      # >= 64 (batch, head) items of such a shape take the PERSISTENT form (attn_spp_kernel: LDS-DMA double
+                                      # buffer, one workgroup walks several items — more items than CUs in the last case, an odd count per XCD)
+                                      (9, 8, 196, 56), (8, 16, 201, 64), (22, 3, 129, 32), (13, 5, 150, 48), (70, 4, 208, 64), (37, 9, 193, 40),
                                       # head dims 72..96 take the wide class (128-half LDS rows, 3 k-steps, 6 output blocks)
                                       (2, 3, 201, 80), (1, 2, 64, 96), (2, 2, 15, 72), (1, 1, 700, 88)])
 def test_attention_flat(cuda, B, H, T, hd):
@@ -277,7 +280,10 @@ def _window_ref(x_q, x_k, x_v, Gh, Gw, ws, heads, hd, pad_k, pad_v, q_stride=1):
                                                     # 4 x 4 windows take the one-wave-per-window kernel: padded grids, Q-pool
                                                     # (4 queries), an item count that is not a multiple of 4
                                                     (1, 12, 12, 4, 2, 56, 2), (2, 10, 10, 4, 5, 56, 1), (1, 8, 8, 4, 1, 32, 1),
-                                                    (1, 20, 20, 14, 2, 80, 1), (1, 12, 12, 4, 2, 80, 1)])
+                                                    (1, 20, 20, 14, 2, 80, 1), (1, 12, 12, 4, 2, 80, 1),
+                                                    # 14 x 14 windows with >= 64 (window, head) items: the persistent kernel, with
+                                                    # padded windows on both edges (64 = 4 * 14 + 8; 30 x 44), head-dim padding, hd 64
+                                                    (3, 64, 64, 14, 4, 56, 1), (2, 30, 44, 14, 8, 32, 1), (1, 64, 64, 14, 8, 64, 1), (12, 28, 28, 14, 2, 56, 1)])
 def test_attention_window(cuda, n, Gh, Gw, ws, heads, hd, qs):
     from lmx import kernels as Kk
 
