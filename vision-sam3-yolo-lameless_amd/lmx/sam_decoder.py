@@ -221,9 +221,9 @@ class MaskDecoder:
     # ---- exact plan: f32 activations, x3 operands (csrc/exact.hip), f32 attention ---------------------------------------
     def _lin(self, x, name, act_in=K.ACT_NONE, act=K.ACT_NONE, res=None, w2d=None, bias=None):
         """y = act(act_in(x) @ W^T + b) (+ res) with 22-bit operands: x f32 [rows, K] is split into x3 rows (after act_in),
-        W into [whi | whi/2048 | wlo] rows pre-scaled by powers of two (lmx.yolo.split_rows_x3), ONE lmx_k_gemm launch over
+        W into [whi | whi/2048 | wlo] rows pre-scaled by powers of two (lmx.exact.split_rows_x3), ONE lmx_k_gemm launch over
         3K with f32 output.  act may be NONE or RELU (it commutes with the positive row scale)."""
-        from .yolo import split_rows_x3
+        from .exact import split_rows_x3
 
         if name not in self._wx:
             w = self._sd[name + ".weight"] if w2d is None else w2d
