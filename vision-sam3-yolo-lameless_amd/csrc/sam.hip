@@ -12,9 +12,16 @@ inline int grid_for(int64_t total, int block = 256) {
 }
 
 // thread = one 8-column chunk of one output row (token); builds the 8 normalised values and stores 16 bytes.
+// KW_T > 0: the kernel width as a compile-time constant (7: Hiera's patch embedding, 16: the SAM ViT's) — the two divisions per
+// VALUE by run-time widths made this kernel ALU-bound at 1.3 TB/s of output; the look-up table sits in LDS.
+template <int KW_T>
 __global__ __launch_bounds__(256) void im2col_u8_kernel(const uint8_t* __restrict__ img, const float* __restrict__ lut,
                                                         half_t* __restrict__ out, int n, int rh, int rw, int OH, int OW, int KH,
-                                                        int KW, int stride, int pad, int64_t ldo) {
+                                                        int KW_rt, int stride, int pad, int64_t ldo) {
+  __shared__ float lut_s[768];
+  for (int i = threadIdx.x; i < 768; i += blockDim.x) lut_s[i] = lut[i];
+  __syncthreads();
+  const int KW = KW_T > 0 ? KW_T : KW_rt;
   const int chunks = (int)(ldo / 8);
   const int K = KH * KW * 3;
   const int64_t total = (int64_t)n * OH * OW * chunks;
@@ -25,6 +32,8 @@ __global__ __launch_bounds__(256) void im2col_u8_kernel(const uint8_t* __restric
     const int64_t r = tok / OW;
     const int oy = (int)(r % OH);
     const int b = (int)(r / OH);
+    const uint8_t* ib = img + (int64_t)b * rh * rw * 3;
+    const int y0 = oy * stride - pad, x0 = ox * stride - pad;
     half8_t v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -33,9 +42,8 @@ __global__ __launch_bounds__(256) void im2col_u8_kernel(const uint8_t* __restric
       if (k < K) {
         const int tap = k / 3, c = k - tap * 3;
         const int ky = tap / KW, kx = tap - ky * KW;
-        const int y = oy * stride - pad + ky, x = ox * stride - pad + kx;
-        if ((unsigned)y < (unsigned)rh && (unsigned)x < (unsigned)rw)
-          val = lut[c * 256 + img[(((int64_t)b * rh + y) * rw + x) * 3 + c]];
+        const int y = y0 + ky, x = x0 + kx;
+        if ((unsigned)y < (unsigned)rh && (unsigned)x < (unsigned)rw) val = lut_s[c * 256 + ib[(y * rw + x) * 3 + c]];
       }
       v[e] = (half_t)val;
     }
@@ -357,9 +365,16 @@ extern "C" int lmx_k_im2col_u8(const uint8_t* img, const float* lut, void* out, 
               "lmx_k_im2col_u8: geometry");
   LMX_REQUIRE(ldo % 8 == 0 && ldo >= (int64_t)KH * KW * 3 && aligned16(out), "lmx_k_im2col_u8: ldo/alignment");
   const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
-  hipLaunchKernelGGL(im2col_u8_kernel, dim3(grid_for((int64_t)n * OH * OW * (ldo / 8))), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), img, lut, reinterpret_cast<half_t*>(out), n, rh, rw, OH, OW, KH, KW,
-                     stride, pad, ldo);
+  LMX_REQUIRE((int64_t)rh * rw * 3 < 0x7fffffffll, "lmx_k_im2col_u8: frame too large");
+  const dim3 grid(grid_for((int64_t)n * OH * OW * (ldo / 8)));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  half_t* o16 = reinterpret_cast<half_t*>(out);
+  if (KW == 7)
+    hipLaunchKernelGGL((im2col_u8_kernel<7>), grid, dim3(256), 0, st, img, lut, o16, n, rh, rw, OH, OW, KH, KW, stride, pad, ldo);
+  else if (KW == 16)
+    hipLaunchKernelGGL((im2col_u8_kernel<16>), grid, dim3(256), 0, st, img, lut, o16, n, rh, rw, OH, OW, KH, KW, stride, pad, ldo);
+  else
+    hipLaunchKernelGGL((im2col_u8_kernel<0>), grid, dim3(256), 0, st, img, lut, o16, n, rh, rw, OH, OW, KH, KW, stride, pad, ldo);
   return lmx_launch_check("im2col_u8_kernel");
 }
 
