@@ -8,6 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vision-sam3-yolo-lameless_amd"), os.path.join(ROOT, "tools")]
+os.environ.setdefault("LMX_MLP448", "1")  # the D = 448 instantiation is a development configuration (csrc/mlp.hip)
 from lmx import kernels as K  # noqa: E402
 from perf_probe import timeit  # noqa: E402
 

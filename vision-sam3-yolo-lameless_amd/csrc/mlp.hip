@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
                                                                           half_t* __restrict__ x16,
                                                                           const float* __restrict__ gam_n,
                                                                           const float* __restrict__ bet_n,
-                                                                          half_t* __restrict__ h_n) {
+                                                                          half_t* __restrict__ h_n, const int stagger) {
   constexpr int KS = (D + 31) / 32;           // k-steps of the first GEMM
   constexpr int DP = D <= 128 ? 128 : (D <= 256 ? 256 : 512);  // halfs per LDS row of a W1 chunk (power of two: XOR swizzle stays in the row)
   constexpr int DB = D / 16;                  // 16-wide output blocks
@@ -192,7 +192,12 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
     else
       wait_vmcnt<0>();  // (a two-slot ring, LA = 1: only chunk c itself is outstanding here)
     __builtin_amdgcn_s_barrier();  // (also publishes b1s on the first pass)
-    if (c + LA < NCH) issue(c + LA, (c + LA) % NST);
+    // Issuing a wave's PT LDS-DMA pieces blocks THAT wave for ~300 cycles per piece (profiles/r03_attn_spp.txt) but not its SIMD.
+    // stagger: the two waves of a SIMD (w and w + NW/2) issue at different points of the chunk — the first before its fc1 MFMAs, the
+    // second after them — so that one computes while the other sits in the vector-memory queue.  (The slot being refilled was
+    // last read in the previous iteration, which the barrier above has closed: any point of this iteration is safe.)
+    const bool late_issue = stagger && wave >= NW / 2;
+    if (!late_issue && c + LA < NCH) issue(c + LA, (c + LA) % NST);
     const char* st = smem + (c % NST) * STAGE;
     const half_t* W1c = reinterpret_cast<const half_t*>(st);
     const char* W2c = st + W1_BYTES;
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
         for (int qb = 0; qb < QB; ++qb) sacc[qb][hb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[qb][ks], sacc[qb][hb], 0, 0, 0);
       }
     }
+    if (late_issue && c + LA < NCH) issue(c + LA, (c + LA) % NST);
     // ---- P = f16(gelu(H^T)): accumulator element i of block hb is hidden unit 16hb + 4fg + i of token fr — exactly
     // k-slot 8fg + (4hb + i) of the next MFMA's B operand once W2's columns are read in the same permuted order
     half8_t pf[QB];
@@ -319,8 +325,13 @@ int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const floa
   const int64_t per = NW * 16 * QB;
   const int64_t nb = (rows + per - 1) / per;
   LMX_REQUIRE(nb < 0x7fffffffll, "lmx_k_ln_mlp: too many rows");
+  // staggered LDS-DMA issue (see the kernel): -3 % at D = 224, -6 % at D = 448, neutral at D = 112 (four waves at three workgroups
+  // per CU are de-phased anyway); identical bits.  LMX_MLP_STAGGER=0 / 1 overrides.
+  static int stagger_env = -2;
+  if (stagger_env == -2) stagger_env = getenv("LMX_MLP_STAGGER") ? atoi(getenv("LMX_MLP_STAGGER")) : -1;
+  const int stagger = stagger_env >= 0 ? stagger_env : (D >= 224 ? 1 : 0);
   hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC, INLN>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, hn, gam, bet, eps, w1, b1, w2,
-                     b2, rows, x16, gam_n, bet_n, h_n);
+                     b2, rows, x16, gam_n, bet_n, h_n, stagger);
   return lmx_launch_check("ln_mlp_kernel");
 }
 
@@ -331,7 +342,8 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
                             const void* w2, const float* b2, int64_t rows, int D, float eps, void* workspace, void* x16,
                             const float* gamma_next, const float* beta_next, void* h_next, lmx_stream_t stream) {
   LMX_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && workspace, "lmx_k_ln_mlp: null pointer");
-  LMX_REQUIRE(D == 112 || D == 224, "lmx_k_ln_mlp: D=%d (built for the Hiera stage widths 112 and 224)", D);
+  // (D = 448 is a development configuration: instantiated, measured slower than the unfused launches, reachable only with LMX_MLP448 set)
+  LMX_REQUIRE(D == 112 || D == 224 || (D == 448 && getenv("LMX_MLP448")), "lmx_k_ln_mlp: D=%d (built for the Hiera stage widths 112 and 224)", D);
   LMX_REQUIRE(rows > 0 && rows < 0x7fffffffll && ldx >= D && ldx % 4 == 0, "lmx_k_ln_mlp: rows=%lld ldx=%lld", (long long)rows,
               (long long)ldx);
   LMX_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(beta) && aligned16(w1) && aligned16(b1) && aligned16(w2) && aligned16(b2) &&
@@ -351,11 +363,17 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
     split_ln = getenv("LMX_MLP_SPLIT_LN") ? 1 : 0;  // the round-1 form: a LayerNorm launch into the workspace, then the fused MLP on it
   }
   // D = 112: 4 waves x 32 tokens, 48 KB ring, three workgroups per CU.  D = 224: 8 waves x 32 tokens, 128 KB ring, one per CU.
-  // (D = 448 — Hiera-B+ stage 3 — was instantiated in round 3 as launch<448, 2, 4, 2, 1, true>: 4 waves x 32 tokens, one wave per
-  // SIMD with 224 accumulator + 112 operand registers, 2 x 64 KB ring.  Correct, and SLOWER than the unfused launches: 1.03 ms
-  // against 0.76 ms for LayerNorm + fc1 + fc2 + the next LayerNorm at 122 880 tokens (profiles/r03_fused_mlp_d448.txt): every
-  // 128-token tile streams all 3.2 MB of weights through LDS with ONE chunk in flight and nothing to hide the per-chunk waits
-  // behind at one wave per SIMD.  Not dispatched; the template still accepts the width for further work.)
+  // D = 448 (Hiera-B+ stage 3), round 3: two configurations, both correct, neither faster than the unfused launches at 122 880 tokens
+  // (LayerNorm + fc1 + fc2 = 0.69 ms; profiles/r03_fused_mlp_d448.txt): LMX_MLP448=2: 4 waves x 32 tokens, one wave per SIMD (336
+  // token registers), 2 x 64 KB ring: 1.03 ms; LMX_MLP448=1: 8 waves x 16 tokens, two per SIMD: 0.72 ms, 0.69 ms with staggered
+  // issue.  Every 128-token tile streams all 3.2 MB of weights through LDS with ONE 64 KB chunk in flight (the ring holds two), 56
+  // chunks each behind a vmcnt(0) + barrier.  Not dispatched by lmx/sam.py.
+  if (D == 448) {
+    static int v448 = -1;
+    if (v448 < 0) v448 = getenv("LMX_MLP448") ? atoi(getenv("LMX_MLP448")) : 1;
+    if (v448 == 2) return launch<448, 2, 4, 2, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+    return launch<448, 1, 8, 2, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  }
   if (!split_ln) {
     if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
     if (D == 112) return launch<112, 2, 8, 4, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);

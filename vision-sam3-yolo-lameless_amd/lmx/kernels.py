@@ -245,7 +245,7 @@ def pack_bits(mask):
     return out
 
 
-FUSED_MLP_WIDTHS = (112, 224)
+FUSED_MLP_WIDTHS = (112, 224)  # (448 exists as a development configuration: slower than the unfused launches, csrc/mlp.hip)
 
 
 def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps, x16=None, next_ln=None):
