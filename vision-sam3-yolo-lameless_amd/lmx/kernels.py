@@ -2,6 +2,7 @@
 every function below checks shapes/strides on the host, fills the C descriptor and enqueues ONE liblmx kernel on
 torch's current HIP stream.  No arithmetic happens in Python and there is no fallback path."""
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -245,7 +246,9 @@ def pack_bits(mask):
     return out
 
 
-FUSED_MLP_WIDTHS = (112, 224)  # (448 exists as a development configuration: slower than the unfused launches, csrc/mlp.hip)
+FUSED_MLP_WIDTHS = (112, 224)  # (448 exists as a development configuration: no faster than the unfused launches, csrc/mlp.hip)
+if os.environ.get("LMX_MLP448"):  # development A/B only
+    FUSED_MLP_WIDTHS = (112, 224, 448)
 
 
 def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps, x16=None, next_ln=None):
