@@ -29,7 +29,7 @@ constexpr int HC = 32;   // hidden units per chunk (one MFMA k-step of the secon
 // rows a LayerNorm launch wrote: saves that launch and 4D bytes per token.  Round 1 had to take it out — a few hundred rows
 // per million got run-to-run different statistics whenever MFMA waves shared the SIMD; round 2 traced that to the SLP
 // vectoriser's v_pk_add_f32 op_sel:[0,1] in the horizontal sums, which the build now forbids.
-template <int D, int QB, int NW, int NST, int OCC, bool INLN>
+template <int D, int QB, int NW, int NST, int OCC, bool INLN, bool RING = false>
 __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __restrict__ x, int64_t ldx,
                                                                           const half_t* __restrict__ hn,
                                                                           const float* __restrict__ gam,
@@ -214,6 +214,25 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
       }
     }
     // ---- H^T = W1c . LN(x)^T
+    if constexpr (RING) {
+      // W1 fragments through a three-deep register ring, two reads ahead of their MFMAs: left alone hipcc (at the register cap)
+      // emits read -> s_waitcnt -> MFMAs per fragment, an LDS latency per 16 - 32 cycles of matrix work (profiles/r03_fused_mlp_d448.txt)
+      auto w1read = [&](int i) {  // i = ks * 2 + hb
+        const int ks = i >> 1, row = (i & 1) * 16 + fr;
+        return *reinterpret_cast<const half8_t*>(W1c + row * DP + (((ks * 4 + fg) ^ (row & 15)) << 3));
+      };
+      half8_t ring[3];
+      ring[0] = w1read(0);
+      ring[1] = w1read(1);
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {
+        if (i + 2 < 2 * KS) ring[(i + 2) % 3] = w1read(i + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[i % 3], xn[qb][i >> 1], sacc[qb][i & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -223,6 +242,7 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) sacc[qb][hb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[qb][ks], sacc[qb][hb], 0, 0, 0);
       }
+    }
     }
     if (late_issue && c + LA < NCH) issue(c + LA, (c + LA) % NST);
     // ---- P = f16(gelu(H^T)): accumulator element i of block hb is hidden unit 16hb + 4fg + i of token fr — exactly
@@ -242,16 +262,33 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
     }
     // ---- O^T += W2[:, chunk] . P.  W2 chunk row = 64 B = four 16-B pieces, piece p stored at p ^ ((row >> 2) & 3);
     // the fragment is hidden units 4fg..4fg+3 (piece fg>>1) and 16+4fg..+3 (piece 2 + (fg>>1)), 8 bytes each
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
+    auto w2read = [&](int db) {
       const int row = db * 16 + fr;
       const int sw = (row >> 2) & 3;
       const char* wr = W2c + row * 64 + (fg & 1) * 8;
       const half4_t lo = *reinterpret_cast<const half4_t*>(wr + (((fg >> 1)) ^ sw) * 16);
       const half4_t hi = *reinterpret_cast<const half4_t*>(wr + ((2 + (fg >> 1)) ^ sw) * 16);
-      const half8_t a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    if constexpr (RING) {
+      half8_t ring[3];
+      ring[0] = w2read(0);
+      ring[1] = w2read(1);
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[qb], oacc[qb][db], 0, 0, 0);
+      for (int db = 0; db < DB; ++db) {
+        if (db + 2 < DB) ring[(db + 2) % 3] = w2read(db + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[db % 3], pf[qb], oacc[qb][db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const half8_t a = w2read(db);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[qb], oacc[qb][db], 0, 0, 0);
+      }
     }
   }
 
@@ -311,14 +348,14 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
   }
 }
 
-template <int D, int QB, int NW, int NST, int OCC, bool INLN>
+template <int D, int QB, int NW, int NST, int OCC, bool INLN, bool RING = false>
 int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const float* bet, float eps, const half_t* w1, const float* b1,
            const half_t* w2, const float* b2, int64_t rows, half_t* x16, const float* gam_n, const float* bet_n, half_t* h_n, hipStream_t st) {
   constexpr int DP = D <= 128 ? 128 : (D <= 256 ? 256 : 512);
   const size_t smem = (size_t)NST * (HC * DP * 2 + DP * 64) + 4 * D * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mlp_kernel<D, QB, NW, NST, OCC, INLN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mlp_kernel<D, QB, NW, NST, OCC, INLN, RING>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
     attr_set = true;
   }
@@ -330,7 +367,7 @@ int launch(float* x, int64_t ldx, const half_t* hn, const float* gam, const floa
   static int stagger_env = -2;
   if (stagger_env == -2) stagger_env = getenv("LMX_MLP_STAGGER") ? atoi(getenv("LMX_MLP_STAGGER")) : -1;
   const int stagger = stagger_env >= 0 ? stagger_env : (D >= 224 ? 1 : 0);
-  hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC, INLN>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, hn, gam, bet, eps, w1, b1, w2,
+  hipLaunchKernelGGL((ln_mlp_kernel<D, QB, NW, NST, OCC, INLN, RING>), dim3((unsigned)nb), dim3(NW * 64), smem, st, x, ldx, hn, gam, bet, eps, w1, b1, w2,
                      b2, rows, x16, gam_n, bet_n, h_n, stagger);
   return lmx_launch_check("ln_mlp_kernel");
 }
@@ -373,6 +410,15 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
     if (v448 < 0) v448 = getenv("LMX_MLP448") ? atoi(getenv("LMX_MLP448")) : 1;
     if (v448 == 2) return launch<448, 2, 4, 2, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
     return launch<448, 1, 8, 2, 1, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  }
+  // fragment reads through a register ring (RING): D = 224 0.72 -> 0.68 ms per 524 288 tokens, D = 112 0.88 -> 0.87 ms, identical bits
+  // (tools/mlp_ab.sh); LMX_MLP_RING=0 is the plain form, 2 the ring with D = 112 at two workgroups per CU (no better)
+  static int ring = -1;
+  if (ring < 0) ring = getenv("LMX_MLP_RING") ? atoi(getenv("LMX_MLP_RING")) : 1;
+  if (ring && !split_ln && D != 448) {
+    if (D == 112 && ring == 2) return launch<112, 2, 4, 3, 2, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+    if (D == 112) return launch<112, 2, 4, 3, 3, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+    return launch<224, 2, 8, 4, 1, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
   }
   if (!split_ln) {
     if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
