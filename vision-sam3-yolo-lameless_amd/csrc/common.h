@@ -100,10 +100,11 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst_l
   if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8 || N == 9 || N == 12 || N == 16 || N == 18 || N == 24 ||
+  static_assert(N == 0 || N == 1 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8 || N == 9 || N == 12 || N == 16 || N == 18 || N == 24 ||
                     N == 32,
                 "add the literal for this count");
   LMX_WAIT_CASE(0);
+  LMX_WAIT_CASE(1);
   LMX_WAIT_CASE(2);
   LMX_WAIT_CASE(3);
   LMX_WAIT_CASE(4);

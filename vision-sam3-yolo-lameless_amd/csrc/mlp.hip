@@ -415,10 +415,24 @@ extern "C" int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const flo
   // (tools/mlp_ab.sh); LMX_MLP_RING=0 is the plain form, 2 the ring with D = 112 at two workgroups per CU (no better)
   static int ring = -1;
   if (ring < 0) ring = getenv("LMX_MLP_RING") ? atoi(getenv("LMX_MLP_RING")) : 1;
+  static int cfg = -1;  // development: LMX_MLP_CFG selects experimental tilings (tools/mlp_ab.sh)
+  if (cfg < 0) cfg = getenv("LMX_MLP_CFG") ? atoi(getenv("LMX_MLP_CFG")) : 0;
+  if (cfg == 3 && D == 224) return launch<224, 1, 8, 2, 2, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  if (cfg == 3 && D == 112) return launch<112, 1, 4, 2, 4, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  if (cfg == 4 && D == 224) return launch<224, 1, 8, 3, 1, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  if (cfg == 4 && D == 112) return launch<112, 1, 8, 2, 2, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  if (cfg == 5 && D == 224) return launch<224, 1, 16, 4, 1, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  if (cfg == 5 && D == 112) return launch<112, 1, 16, 4, 1, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  if (cfg == 6 && D == 224) return launch<224, 1, 8, 2, 2, true, false>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+  if (cfg == 6 && D == 112) return launch<112, 2, 8, 2, 2, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
   if (ring && !split_ln && D != 448) {
     if (D == 112 && ring == 2) return launch<112, 2, 4, 3, 2, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
     if (D == 112) return launch<112, 2, 4, 3, 3, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
-    return launch<224, 2, 8, 4, 1, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+    // D = 224: 16 tokens per wave (84 token registers instead of 168), 8 waves, TWO workgroups per CU on 2 x 32 KB rings: four waves
+    // per SIMD hide the fragment-read latency that two could not — 0.73 -> 0.63 ms per 524 288 tokens (tools/mlp_ab.sh: cfg 3 against
+    // the 32-token form, LMX_MLP_CFG=7); at D = 112 the 32-token form at three workgroups per CU stays ahead (0.88 vs 1.01 ms)
+    if (cfg == 7) return launch<224, 2, 8, 4, 1, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
+    return launch<224, 1, 8, 2, 2, true, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
   }
   if (!split_ln) {
     if (D == 112 && !one_per_cu) return launch<112, 2, 4, 3, 3, true>(x, ldx, nullptr, gamma, beta, eps, W1, b1, W2, b2, rows, X16, gamma_next, beta_next, HN, st);
