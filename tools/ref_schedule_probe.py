@@ -46,3 +46,14 @@ for prec in ("exact", "f16"):
     ev = sum(r["seconds"] for r in tr.values()) * 1e3
     print(f"reference schedule (SAM passes of {CH}), plans {prec:5s}: {ms:6.2f} ms per clip on the step's streams, {ms1:6.2f} ms on one stream; {nl} C-ABI launches per clip, "
           f"event-timed kernel time {ev:6.2f} ms", flush=True)
+
+if os.environ.get("LMX_REF_SHAPES"):  # per-shape table of one exact-plan clip (serialized, event-timed)
+    fx.serial = True
+    K.start_launch_trace()
+    for _ in range(3):
+        fx.step(sf, sam_chunk=CH, det_idx=det, emb_idx=emb, precision="exact")
+    _, shapes = K.stop_launch_trace(by_shape=True)
+    tot = sum(r["seconds"] for r in shapes.values())
+    print(f"# reference schedule, exact plans: {tot / 3 * 1e3:.2f} ms per clip (event-timed, one stream); top shapes:")
+    for (cls, key), r in sorted(shapes.items(), key=lambda kv: -kv[1]["seconds"])[:30]:
+        print(f"{100 * r['seconds'] / tot:5.1f}%  {r['launches'] // 3:3d}x {r['seconds'] / r['launches'] * 1e6:7.1f} us  {r['flops'] / max(r['seconds'], 1e-12) / 1e12:6.0f} TF  {r['bytes'] / max(r['seconds'], 1e-12) / 1e9:6.0f} GB/s  [{cls}] {key}")
