@@ -317,7 +317,13 @@ extern "C" int lmx_k_gemm(const lmx_gemm_desc* dp, lmx_stream_t stream) {
   // large dense problems take the LDS-DMA 256x128 kernel (gemm2.hip); small / narrow ones and the conv generator stay here
   const bool conv_ok = d.a_mode == 1 && d.Cin % 32 == 0 && d.H < 32768 && d.W_ < 32768;  // (f32 out: the exact plan's pre-activations)
   if (d.a_mode == 2) return lmx_gemm2_launch(d, st);
-  if ((d.a_mode == 0 || conv_ok) && d.M >= 512 && d.N >= 96 && d.N % 8 == 0 && d.ldc % 8 == 0 && (!d.res || d.ldr % 8 == 0) &&
+  // (3 x 3 convolutions with 64 output channels — YOLOv8-l's first C2f stage and Detect's box branch: 2.3 M rows at 150 frames — also
+  // take the LDS-DMA kernel: half of its 128-wide n-tile is zero-filled, but these launches are bound by A staging, not by the MFMA:
+  // LMX_GEMM_N64=0 restores the register-staged kernel for them)
+  static int n64 = -1;
+  if (n64 < 0) n64 = (getenv("LMX_GEMM_N64") && getenv("LMX_GEMM_N64")[0] == '0') ? 0 : 1;
+  const int n_min = (conv_ok && n64 && d.M >= 65536) ? 64 : 96;
+  if ((d.a_mode == 0 || conv_ok) && d.M >= 512 && d.N >= n_min && d.N % 8 == 0 && d.ldc % 8 == 0 && (!d.res || d.ldr % 8 == 0) &&
       aligned16(d.C) && (!d.res || aligned16(d.res)) && !force_v1())
     return lmx_gemm2_launch(d, st);
   if (d.a_mode == 0) {
