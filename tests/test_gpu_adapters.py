@@ -175,3 +175,46 @@ def test_dino_adapter_reference_idiom(cuda, tmp_path):
     # dummy forward for the embedding size (dinov3 main.py:74-78 builds a dummy image for _ensure_collection)
     dummy = processor(images=Image.new("RGB", (224, 224)), return_tensors="pt").to(device)
     assert model(**dummy).last_hidden_state.mean(dim=1).shape[-1] == 192
+
+
+def test_single_frame_calls_replay_hip_graphs_with_identical_results(cuda, monkeypatch):
+    """lmx/graphs.py (LMX_GRAPHS=1): the adapters capture a single-frame call once per input shape and replay it.  Over a sequence of different
+    frames (and prompts) the replayed results are byte-identical to the eager calls (LMX_GRAPHS=0), the capture happened exactly
+    once, and a result handed out earlier is not overwritten by a later call."""
+    from PIL import Image
+
+    from lmx import adapters, dino, sam, sam_decoder, synth, weights, yolo
+
+    frames = [synth.synth_frame(3 + i, 40 - 7 * i) for i in range(3)]
+    ycfg = yolo.YoloConfig("n")
+    ymodel = adapters.LmxYolo((ycfg, yolo.synthetic_state_dict(ycfg, 7, yolo.bn_stats_path("n"))), device=cuda)
+    scfg = sam.SamVitConfig(hidden=128, layers=3, heads=2, mlp=256, global_idx=(1,), window=14, image=1024)
+    ssd = weights.synth_state_dict(sam.vit_param_spec(scfg), 61)
+    ssd.update(sam_decoder.synthetic_state_dict(62))
+    pred = adapters.SamPredictor(adapters.LmxSam(scfg, ssd, cuda))
+    dcfg = dino.DinoConfig(arch="dinov2", hidden=192, layers=3, heads=3, mlp=768, patch=14, registers=0, eps=1e-6, pos_grid=37)
+    dmodel = adapters.LmxDinoModel(dcfg, weights.synth_state_dict(dino.param_spec(dcfg), 22), cuda)
+    proc = adapters.LmxImageProcessor(dmodel)
+    boxes = [np.array([420.0, 360.0, 1010.0, 850.0]), np.array([100.0, 100.0, 900.0, 700.0]), np.array([800.0, 200.0, 1700.0, 1000.0])]
+
+    def run_all():
+        out = []
+        for fr, bx in zip(frames, boxes):
+            r = ymodel(fr, verbose=False, conf=0.25)[0]
+            pred.set_image(fr)
+            m, s, low = pred.predict(box=bx[None, :], multimask_output=False)
+            h = dmodel(**proc(images=Image.fromarray(np.ascontiguousarray(fr[:, :, ::-1])), return_tensors="pt").to(cuda)).last_hidden_state
+            out.append((r.boxes.xyxy, r.boxes.conf, r.boxes.cls, m, s, low, h))
+        return [[t.cpu().numpy() if isinstance(t, torch.Tensor) else t for t in row] for row in out]  # read AFTER the last call
+
+    monkeypatch.setenv("LMX_GRAPHS", "1")
+    graphed = run_all()
+    fns = [next(iter(ymodel._graphs.values())), pred._g_encode, next(iter(pred._g_decode.values())), dmodel._g_hidden, dmodel._g_pre]
+    assert all(not g.failed and len(g.cache) == 1 for g in fns), [(g.failed, len(g.cache)) for g in fns]
+    monkeypatch.setenv("LMX_GRAPHS", "0")
+    eager = run_all()
+    assert len(graphed[0][0]) > 0 and any(m[3].any() for m in graphed)
+    for a, b in zip(graphed, eager):
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and x.dtype == y.dtype and x.tobytes() == y.tobytes()
+    assert not np.array_equal(graphed[0][6], graphed[1][6])  # the frames differ, and so do their results

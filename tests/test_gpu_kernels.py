@@ -225,6 +225,8 @@ def _attn_ref(q, k, v, scale):
 # T >= 256 takes the LDS-DMA ring (attn.hip DMA path): ragged last tile, head-dim padding chunks, one / many key tiles
 @pytest.mark.parametrize("B,H,T,hd", [(2, 16, 201, 64), (3, 2, 64, 56), (1, 4, 300, 32), (2, 3, 16, 64), (1, 2, 1000, 56),
                                       (2, 3, 257, 64), (3, 2, 256, 56), (1, 2, 4096, 56), (2, 1, 1153, 48),
+                                      # (the pipelined form attn_gp_kernel: odd / even tile counts, full and ragged last tile, dot2 sums)
+                                      (1, 4, 320, 64), (1, 1, 4032, 56), (2, 2, 258, 40), (1, 2, 384, 64),
                                       # 128 < T <= 208 takes the whole-sequence kernel (attn_sp_kernel): both edges, a ragged
                                       # last 16-key block, an odd number of 16-query blocks, head-dim padding, ones-column / dot2 sums
                                       (2, 8, 196, 56), (1, 3, 208, 64), (2, 2, 129, 32), (3, 5, 150, 48), (1, 2, 193, 64), (2, 1, 209, 56),

@@ -454,6 +454,364 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
 }
 
 
+// ---- long flat sequences, software-pipelined (round 3; Hiera's global blocks: T = 4096, head dim 56).  attn_kernel's LDS-DMA
+// form issues, per 64-key tile and wave, 16 S MFMAs, then ~180 VALU instructions of softmax that depend on them, then 16 PV MFMAs
+// that depend on those, and — its LDS images being static __shared__ arrays — hipcc puts `s_waitcnt vmcnt(0)` in front of the
+// first fragment read after every DMA issue, so its ring never has a tile in flight.  Here:
+//  * the images are DYNAMIC LDS and V's transposed reads are inline asm (the builtin form gets the same conservative wait), so the
+//    counted waits are the only ones and two groups of DMAs stay in flight;
+//  * the K ring runs ONE TILE AHEAD of the V ring and the wave issues S(i+1) before the softmax of tile i: the next tile's MFMAs
+//    run under this tile's exponentials inside the same wave (a second accumulator set, 32 registers; sched_group_barrier
+//    interleaves one MFMA per four VALU instructions);
+//  * the one wave-uniform branch of a tile (did a running maximum grow? then rescale) sits before that block;
+//  * the row maximum is v_max3_f32 (fmaxf on MFMA results costs hipcc a canonicalising v_max per operand) and its cross-lane step
+//    v_permlane16_swap / v_permlane32_swap instead of two ds_bpermute round trips in the middle of the dependency chain.
+// Same MFMA order per accumulator, same exp2 arguments, same f16 roundings as attn_kernel<2, ONES, false, true, 64>: identical
+// bits (tools/attn_gp_probe.py), 1601 -> 1518 us at B = 30, H = 8 (profiles/r03_attn_gp.txt).  What the time is made of
+// (-DLMX_GP_DBG=n builds, tools/attn_gp_decompose.sh): without the exponentials -10 %, without the row maximum -10 %, without the
+// DMA issue -15 %, without either MFMA group and its fragment reads -32 % each: the phases add up — per wave and tile ~1200 issue
+// cycles (32 MFMAs hold the vector issue for 8 of their 16 cycles, 34 v_exp_f32 at 8, ~150 other VALU at 4, 4 DMA pieces at
+// 60 - 100) against 512 matrix cycles.  At head dim 64 a score costs the same softmax as at 128 and feeds half the MFMA work.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// maximum over the four 16-lane rows of a wave, delivered to every row (lane maps: tools/permlane_swap_probe.hip).  Two traps:
+// __builtin_bit_cast(float, a[1]) on an element of the returned 2-vector reads element 0 (hipcc 7.2 takes the vector's address):
+// the maximum then covered one row only — still a valid softmax shift, so only the bit-for-bit comparison with the shuffle form
+// showed it — hence the scalar temporaries; and the instructions next to a swap stay the compiler's own (fmaxf, not the asm
+// helpers above), because gfx950 needs wait states around v_permlane*_swap that hipcc inserts only for instructions it knows.
+__device__ __forceinline__ float row_max4(float ma, float mc) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned u = __builtin_bit_cast(unsigned, fmaxf(ma, mc));
+  const u32x2 a = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // {r0 r0 r2 r2}, {r1 r1 r3 r3}
+  const unsigned a0 = a[0], a1 = a[1];
+  const unsigned u1 = __builtin_bit_cast(unsigned, fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1)));
+  const u32x2 b = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);  // {lo lo}, {hi hi}
+  const unsigned b0 = b[0], b1 = b[1];
+  return fmaxf(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
+}
+
+#ifndef LMX_GP_DBG
+#define LMX_GP_DBG 0
+#endif
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <bool ONES>
+__global__ __launch_bounds__(256, 2) void attn_gp_kernel(const lmx_attn_desc p, const int nQT) {
+  constexpr int QB = 2, NSL = 3, RW = 64, PT = 4;
+  // DYNAMIC LDS on purpose: for a static __shared__ array hipcc's waitcnt pass knows the LDS-DMA writes and the fragment reads
+  // touch the same object and puts `s_waitcnt vmcnt(0)` in front of the first read after every issue — the ring then never has a
+  // tile in flight (attn_kernel's DMA form has exactly that wait in its loop).  The counted waits below are the synchronisation.
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t (*Ks)[64 * RW] = reinterpret_cast<half_t (*)[64 * RW]>(smem);
+  half_t (*Vs)[64 * RW] = reinterpret_cast<half_t (*)[64 * RW]>(smem + NSL * 64 * RW * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  int bid;
+  {
+    const int n = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = n >> 3, r = n & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int nQTa = nQT < 0 ? -nQT : nQT;
+  const int qt = bid % nQTa;
+  bid /= nQTa;
+  const int h = bid % p.H;
+  const int b = bid / p.H;
+  const half_t* Q = reinterpret_cast<const half_t*>(p.Q);
+  const half_t* K = reinterpret_cast<const half_t*>(p.K);
+  const half_t* V = reinterpret_cast<const half_t*>(p.V);
+  half_t* O = reinterpret_cast<half_t*>(p.O);
+  const int hd = p.hd;
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  const int q_base = qt * 128 + wave * 32;
+  half8_t qf[QB][2];
+  int64_t qrow[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int tq = q_base + qb * 16 + fr;
+    qrow[qb] = (tq < p.Tq) ? (int64_t)b * p.Tq + tq : -1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int d = ks * 32 + fg * 8;
+      const bool ok = qrow[qb] >= 0 && d < hd;
+      const half8_t qv = *reinterpret_cast<const half8_t*>(Q + (ok ? qrow[qb] * p.ldq + (int64_t)h * hd + d : 0));
+      qf[qb][ks] = ok ? qv : zero8;
+    }
+  }
+  f32x4 oacc[QB][4];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  const int ntile = (p.Tk + 63) / 64;
+  const int q4 = fr >> 2, p4 = fr & 3;
+
+  // LDS-DMA plan as in attn_kernel: wave w stages pieces 2w, 2w+1 (8 rows x 128 B each) of a K tile and of a V tile
+  const int64_t kbytes = ((int64_t)(p.Tk - 1) * p.ldk + hd) * 2, vbytes = ((int64_t)(p.Tk - 1) * p.ldv + hd) * 2;  // < 2^31: launcher
+  const __amdgpu_buffer_rsrc_t k_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(K + (int64_t)b * p.Tk * p.ldk + (int64_t)h * hd), 0, (int)kbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(V + (int64_t)b * p.Tk * p.ldv + (int64_t)h * hd), 0, (int)vbytes, 0x00020000);
+  unsigned kvo[2], vvo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + (lane >> 3);
+    const int lc = (lane & 7) ^ (row & 7);
+    const bool ok = lc * 8 < hd;
+    kvo[j] = ok ? (unsigned)(row * (int)p.ldk * 2 + lc * 16) : 0x80000000u;
+    vvo[j] = ok ? (unsigned)(row * (int)p.ldv * 2 + lc * 16) : 0x80000000u;
+  }
+  // a tile index past the last one addresses rows >= Tk: outside the descriptor, the DMA writes zeros (into a free slot)
+  auto issue_k = [&](int it) {
+    const unsigned ko = (unsigned)(it * 64 * (int)p.ldk * 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      lds_dma16(k_rs, reinterpret_cast<char*>(&Ks[it % NSL][0]) + (wave * 2 + j) * 1024, kvo[j] == 0x80000000u ? kvo[j] : kvo[j] + ko, 0);
+  };
+  auto issue_v = [&](int it) {
+    const unsigned vo = (unsigned)(it * 64 * (int)p.ldv * 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      lds_dma16(v_rs, reinterpret_cast<char*>(&Vs[it % NSL][0]) + (wave * 2 + j) * 1024, vvo[j] == 0x80000000u ? vvo[j] : vvo[j] + vo, 0);
+  };
+  int k_lane[2], v_lane[4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) k_lane[ks] = fr * RW + ((((ks << 2) + fg) ^ (fr & 7)) << 3);
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const int chunk = db * 2 + (p4 >> 1), rl = fg * 4 + q4;
+    v_lane[db] = rl * RW + ((chunk ^ (rl & 7)) << 3) + (p4 & 1) * 4;
+  }
+  auto s_mfma = [&](int it, f32x4 (&s)[QB][4]) {  // S^T(it) = K(it) . Q^T, raw
+    unsigned kbase[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) kbase[ks] = lds_addr(&Ks[it % NSL][k_lane[ks]]);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) s[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const half8_t kf = lds_read8(kbase[ks], kb * 16 * RW * 2);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qb][ks], s[qb][kb], 0, 0, 0);
+      }
+  };
+
+  // group g of DMAs = { K tile g+1, V tile g }: 4 per wave; K tile 0 goes first on its own
+  issue_k(0);
+  issue_k(1);
+  issue_v(0);
+  if (ntile > 1) {
+    issue_k(2);
+    issue_v(1);
+    wait_vmcnt<8>();
+  } else {
+    wait_vmcnt<4>();
+  }
+  __builtin_amdgcn_s_barrier();
+  f32x4 sA[QB][4], sB[QB][4];
+  s_mfma(0, sA);
+
+  // one key tile: `cur` holds S(it); S(it+1) goes to `nxt`
+  auto step = [&](const int it, f32x4 (&cur)[QB][4], f32x4 (&nxt)[QB][4], auto mask_tag, auto next_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    constexpr bool NEXT = decltype(next_tag)::value;  // a tile it+1 exists
+    const int t0 = it * 64;
+    const int left = ntile - 1 - it;
+    wait_tiles<PT>(left < 1 ? left : 1);  // groups <= it have landed: K(it+1), V(it)
+    __builtin_amdgcn_s_barrier();         // ... for every wave, and every wave is through S(it) and PV(it-1)
+#if LMX_GP_DBG == 5  // decomposition build: no LDS-DMA in the loop (the waits fall through)
+    if (p.Tk < 0)
+#endif
+    if (it + 2 < ntile) {
+      issue_k(it + 3);  // slot of K(it)
+      issue_v(it + 2);  // slot of V(it-1)
+    }
+    // ---- row maxima of S(it) first: the one wave-uniform branch of a tile (did any query's maximum grow?) comes BEFORE the block
+    // that holds the next tile's S MFMAs and this tile's exponentials, so the scheduler can interleave those
+    float nmb[QB], alq[QB];
+    {
+      float alpha[QB];
+      bool grew = nQT < 0;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        if (MASK) {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (t0 + kb * 16 + fg * 4 + r >= p.Tk) cur[qb][kb][r] = -INFINITY;
+        }
+#if LMX_GP_DBG == 4  // decomposition build: no maximum
+        const float m_new = 0.f;
+#else
+        float ma = vmax3(cur[qb][0][0], cur[qb][0][1], cur[qb][0][2]);
+        float mc = vmax3(cur[qb][2][0], cur[qb][2][1], cur[qb][2][2]);
+        ma = vmax3(ma, cur[qb][0][3], cur[qb][1][0]);
+        mc = vmax3(mc, cur[qb][2][3], cur[qb][3][0]);
+        ma = vmax3(ma, cur[qb][1][1], cur[qb][1][2]);
+        mc = vmax3(mc, cur[qb][3][1], cur[qb][3][2]);
+        ma = vmax3(ma, cur[qb][1][3], cur[qb][3][3]);
+        const float m_new = fmaxf(m_run[qb], row_max4(ma, mc));
+#endif
+        grew = grew || __builtin_amdgcn_ballot_w64(m_new > m_run[qb]) != 0;
+        alpha[qb] = (m_run[qb] - m_new) * sl2;
+        alq[qb] = 1.0f;
+        m_run[qb] = m_new;
+        nmb[qb] = -(m_new * sl2);
+      }
+      // the running maximum settles after the first few key tiles: rescale only when some query of the wave raised it
+      // (exp2(0) = 1 for the queries that did not: their accumulators are multiplied by exactly 1)
+      if (grew) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const float al = __builtin_amdgcn_exp2f(alpha[qb]);
+          alq[qb] = al;
+#pragma unroll
+          for (int db = 0; db < 4; ++db) oacc[qb][db] *= al;
+        }
+      }
+    }
+#if LMX_GP_DBG == 2  // decomposition build: no S MFMAs (and no K fragment reads) in the loop
+    if (p.Tk < 0) s_mfma(it + 1, nxt);
+#else
+    if constexpr (NEXT) s_mfma(it + 1, nxt);
+#endif
+    half8_t pf[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float rs = 0.f;
+      const half2_t ones2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 a = {fmaf(cur[qb][kb][r], sl2, nmb[qb]), fmaf(cur[qb][kb][r + 1], sl2, nmb[qb])};
+#if LMX_GP_DBG == 1  // decomposition build: no transcendental
+          const float e0 = a[0], e1 = a[1];
+#else
+          const float e0 = __builtin_amdgcn_exp2f(a[0]);
+          const float e1 = __builtin_amdgcn_exp2f(a[1]);
+#endif
+          const half2_t e = {(half_t)e0, (half_t)e1};
+          if (!ONES) rs = __builtin_amdgcn_fdot2(e, ones2, rs, false);
+          pf[qb][kb >> 1][(kb & 1) * 4 + r] = e[0];
+          pf[qb][kb >> 1][(kb & 1) * 4 + r + 1] = e[1];
+        }
+      if (!ONES) l_run[qb] = l_run[qb] * alq[qb] + rs;
+    }
+#ifndef LMX_ATTN_GP_NOSCHED
+    if constexpr (NEXT) {  // one S MFMA (16 matrix cycles) per four VALU instructions of the exponentials
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      }
+    }
+#endif
+    // ---- O^T += V^T . P^T.  The transposed reads are inline asm: through the builtin hipcc cannot tell them from the LDS-DMA
+    // writes in flight and waits for vmcnt(0) first.  All sixteen are requested, then waited for together.
+#if LMX_GP_DBG == 3  // decomposition build: no PV MFMAs (and no V fragment reads)
+    if (p.Tk < 0)
+#endif
+    {
+    unsigned vbase[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) vbase[db] = lds_addr(&Vs[it % NSL][v_lane[db]]);
+    u32x2_t vt[2][4][2];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[0][db][0]) : "v"(vbase[db]) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vt[0][db][1]) : "v"(vbase[db]) : "memory");
+    }
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vt[1][db][0]) : "v"(vbase[db]) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(vt[1][db][1]) : "v"(vbase[db]) : "memory");
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // (the registers are operands of the wait so that no consumer can be scheduled in front of it)
+#define LMX_VT8(k) "+v"(vt[k][0][0]), "+v"(vt[k][0][1]), "+v"(vt[k][1][0]), "+v"(vt[k][1][1]), "+v"(vt[k][2][0]), "+v"(vt[k][2][1]), "+v"(vt[k][3][0]), "+v"(vt[k][3][1])
+      if (ks == 0)
+        asm volatile("s_waitcnt lgkmcnt(8)" : LMX_VT8(0)::"memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : LMX_VT8(1)::"memory");
+#undef LMX_VT8
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        u32x4_t w = {vt[ks][db][0][0], vt[ks][db][0][1], vt[ks][db][1][0], vt[ks][db][1][1]};
+        if (ONES && db == 3) {  // row d = 63 of V^T (lanes fr == 15) is the ones row: the staged tile holds zeros there
+          const u32x4_t ones4 = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+          w = fr == 15 ? ones4 : w;
+        }
+        const half8_t vf = __builtin_bit_cast(half8_t, w);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][ks], oacc[qb][db], 0, 0, 0);
+      }
+    }
+    }
+#if LMX_GP_DBG == 3
+    for (int qb = 0; qb < QB; ++qb) oacc[qb][0][0] += (float)pf[qb][0][0] + (float)pf[qb][1][7] + (float)pf[qb][0][3] + (float)pf[qb][1][4];
+#endif
+  };
+  const std::true_type T{};
+  const std::false_type F{};
+  int it = 0;
+  for (; it + 2 < ntile; it += 2) {
+    step(it, sA, sB, F, T);
+    step(it + 1, sB, sA, F, T);
+  }
+  const bool part = (p.Tk & 63) != 0;
+  if (it + 2 == ntile) {
+    step(it, sA, sB, F, T);
+    if (part)
+      step(it + 1, sB, sA, T, F);
+    else
+      step(it + 1, sB, sA, F, F);
+  } else {
+    if (part)
+      step(it, sA, sB, T, F);
+    else
+      step(it, sA, sB, F, F);
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    float l;
+    if (ONES) {
+      l = __shfl(oacc[qb][3][3], 48 + fr, 64);
+    } else {
+      l = l_run[qb];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
+    const float inv = 1.0f / l;
+    if (qrow[qb] < 0) continue;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const int d = db * 16 + fg * 4;
+      if (d >= hd) continue;
+      half4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[qb][db][r] * inv);
+      *reinterpret_cast<half4_t*>(O + qrow[qb] * p.ldo + (int64_t)h * hd + d) = o;
+    }
+  }
+}
+
+
 // ---- tiny sequences (Tq <= 16 and Tk <= 16: Hiera's 4 x 4 windows, 16 384 of them per image batch and head).
 // attn_kernel spends a 4-wave workgroup, a 64 x 64 LDS tile and a barrier on each (window, head) and uses 1/16 of its
 // MFMA work; here ONE WAVE owns an item and nothing is shared: Q and K fragments come straight from global memory (a lane's
@@ -1222,8 +1580,9 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   LMX_REQUIRE(nblk < (1ll << 31), "lmx_k_attention: grid too large");
   const bool ones = d.hd <= 56;
   // LDS-DMA staging: flat geometry without bias, at least a few key tiles, per-(batch) K/V extent within a 31-bit buffer
-  static int no_dma = -1, no_lazy = 0;
+  static int no_dma = -1, no_lazy = 0, no_gp = 0;
   if (no_dma < 0) {
+    no_gp = getenv("LMX_ATTN_NO_GP") ? 1 : 0;  // A/B: the unpipelined LDS-DMA form of attn_kernel
     no_dma = getenv("LMX_ATTN_NO_DMA") ? 1 : 0;
     no_lazy = getenv("LMX_ATTN_NO_LAZY") ? 1 : 0;
   }
@@ -1241,6 +1600,10 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
       hipLaunchKernelGGL((attn_kernel<1, false, true, false, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   } else if (wide)
     hipLaunchKernelGGL((attn_kernel<1, false, false, false, 96>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
+  else if (dma && !no_gp && ones)
+    hipLaunchKernelGGL((attn_gp_kernel<true>), dim3((unsigned)nblk), dim3(256), 2 * 3 * 64 * 64 * 2, st, d, nQT);
+  else if (dma && !no_gp)
+    hipLaunchKernelGGL((attn_gp_kernel<false>), dim3((unsigned)nblk), dim3(256), 2 * 3 * 64 * 64 * 2, st, d, nQT);
   else if (dma && ones)
     hipLaunchKernelGGL((attn_kernel<2, true, false, true, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else if (dma)

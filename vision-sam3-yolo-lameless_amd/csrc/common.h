@@ -50,7 +50,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // vc = clamp(v, -4.5, 4.5) and P of degree 9 (weighted least-squares Chebyshev fit, evaluated in f32: |error| <= 3.4e-5
 // for every v, i.e. a tenth of the f16 rounding of an O(1) result; tools/fit_gelu.py reproduces the coefficients).
 // No transcendental (v_rcp / v_exp are quarter rate) and written on 2-vectors so the Horner chain is v_pk_fma_f32:
-// ~7.5 VALU issue slots per value against ~23 for the Abramowitz-Stegun erf it replaces.  At D = 112..448 the GELU of an
+// ~7.5 VALU issue slots per value against ~23 for the Abramowitz-Stegun erf it replaces.  (The same polynomial on scalar v_fma_f32
+// chains — identical bits — measured the same: fused LN + MLP 0.92 / 0.63 ms against 0.88 / 0.64, bench 596.8 against 597.3
+// frames/s, profiles/r03_gelu_scalar_ab.txt.)  At D = 112..448 the GELU of an
 // MLP otherwise costs more VALU time than its two GEMMs cost MFMA time.
 __device__ __forceinline__ f32x2 gelu_pk(f32x2 v) {
   f32x2 vc;

@@ -14,13 +14,19 @@ reference's own `main.py` files run on liblmx with their call sites unchanged (I
 
 Tensors handed back are torch tensors on the device (the glue calls .cpu().numpy() on them, as it does on Ultralytics');
 numpy where segment_anything returns numpy.  Everything between the call and the return runs in liblmx kernels; there is
-no CPU path (a missing library or a CPU-only torch raises)."""
+no CPU path (a missing library or a CPU-only torch raises).
+
+Single-frame calls — the shape of every call the reference's loops make — can be replayed from a HIP graph captured on the first
+call of an input shape (LMX_GRAPHS=1; lmx/graphs.py: same kernels, same bits, one launch instead of 200 - 700).  Measured, the
+replay is no faster than the eager call (the latency is the GPU's chain of small kernels), so it is off by default; it frees the
+host thread.  Calls with several frames always run eagerly."""
 from pathlib import Path
 
 import numpy as np
 import torch
 
 from . import checkpoints, dino, sam, sam_decoder, yolo
+from .graphs import GraphedFn
 
 
 def _device(device):
@@ -100,6 +106,7 @@ class LmxYolo:
         self.detector = yolo.YoloDetector(cfg, sd, self.device, names=names)
         self.names = self.detector.names
         self.task = "pose" if cfg.kpt_shape is not None else "detect"
+        self._graphs = {}  # (conf, iou, max_det) -> GraphedFn over one frame (the thresholds are kernel arguments of the capture)
 
     def to(self, device):  # the stock API allows model.to(...); weights already live on self.device
         return self
@@ -118,10 +125,19 @@ class LmxYolo:
     def __call__(self, source, verbose=False, conf=0.25, iou=0.7, max_det=300, **_unused):
         frames = self._frames(source)
         kp = None
-        if self.task == "pose":
-            boxes, scores, cls, _, counts, kp = self.detector.detect_pose(frames, conf=conf, iou=iou, max_det=max_det)
+        run = self.detector.detect_pose if self.task == "pose" else self.detector.detect
+        if frames.shape[0] == 1:
+            key = (float(conf), float(iou), int(max_det))
+            g = self._graphs.get(key)
+            if g is None and len(self._graphs) < 4:  # a service calls with ONE threshold set; a sweep over many runs eagerly
+                g = self._graphs[key] = GraphedFn(lambda f, k=key: run(f, conf=k[0], iou=k[1], max_det=k[2]))
+            out = g(frames) if g is not None else run(frames, conf=conf, iou=iou, max_det=max_det)
         else:
-            boxes, scores, cls, _, counts = self.detector.detect(frames, conf=conf, iou=iou, max_det=max_det)
+            out = run(frames, conf=conf, iou=iou, max_det=max_det)
+        if self.task == "pose":
+            boxes, scores, cls, _, counts, kp = out
+        else:
+            boxes, scores, cls, _, counts = out
         counts = counts.cpu().tolist()  # one host sync per call (the stock predictor syncs per box: yolo main.py:82-84)
         shape = tuple(frames.shape[1:3])
         out = []
@@ -175,6 +191,10 @@ class LmxSamPredictor:
         self.encoder, self.decoder = sam_model.image_encoder, sam_model.mask_decoder
         self.device = sam_model.device
         self.is_image_set = False
+        # the embedding is a static buffer of the capture (valid until the next set_image: the predictor's own contract); the
+        # decoder's outputs are copied to the host before predict returns
+        self._g_encode = GraphedFn(lambda f: self.encoder.encode(f)["fpn"][2], clone_outputs=False)
+        self._g_decode = {}  # (original_size, input_size) -> GraphedFn(features, box)
 
     @classmethod
     def from_parts(cls, encoder, decoder):
@@ -200,7 +220,7 @@ class LmxSamPredictor:
         frames = torch.from_numpy(np.ascontiguousarray(a)[None]).to(self.device)
         self.original_size = tuple(a.shape[:2])
         self.input_size = sam.resize_longest_side(a.shape[0], a.shape[1], self.encoder.cfg.image)
-        e2 = self.encoder.encode(frames)["fpn"][2]
+        e2 = self._g_encode(frames)
         self.features = e2.reshape(-1, e2.shape[-1])
         self.is_image_set = True
 
@@ -214,7 +234,11 @@ class LmxSamPredictor:
         if multimask_output:
             raise NotImplementedError("lmx decodes the single-mask output (multimask_output=False, sam3 main.py:87)")
         b = torch.from_numpy(np.asarray(box, np.float64).reshape(1, 4).astype(np.float32)).to(self.device)
-        out = self.decoder.predict(self.features, b, self.original_size, self.input_size)
+        key = (self.original_size, self.input_size)
+        g = self._g_decode.get(key)
+        if g is None and len(self._g_decode) < 4:
+            g = self._g_decode[key] = GraphedFn(lambda f, bx, k=key: self.decoder.predict(f, bx, k[0], k[1]), clone_outputs=False)
+        out = g(self.features, b) if g is not None else self.decoder.predict(self.features, b, *key)
         low = out["lowres"].cpu().numpy()
         scores = out["iou"].cpu().numpy()
         if return_logits:
@@ -263,6 +287,8 @@ class LmxDinoModel:
         self.device = _device(device)
         self.embedder = dino.DinoEmbedder(cfg, state_dict, self.device)
         self.config = cfg
+        self._g_hidden = GraphedFn(lambda pv: self.embedder.hidden_states(pv, 1))
+        self._g_pre = GraphedFn(lambda a: self.embedder.preprocess(a, rgb=True))
 
     @classmethod
     def from_pretrained(cls, model_dir, device=None):
@@ -279,7 +305,8 @@ class LmxDinoModel:
         if not isinstance(pixel_values, LmxPixelValues):
             raise TypeError("pixel_values must come from LmxImageProcessor (the patch matrix liblmx reads)")
         B = pixel_values.lmx_batch
-        y = self.embedder.hidden_states(pixel_values.as_subclass(torch.Tensor), B)
+        pv = pixel_values.as_subclass(torch.Tensor)
+        y = self._g_hidden(pv) if B == 1 else self.embedder.hidden_states(pv, B)
         return _Output(y.view(B, self.config.tokens, self.config.hidden))
 
 
@@ -303,5 +330,6 @@ class LmxImageProcessor:
         if arr.dtype != np.uint8 or arr.ndim != 4 or arr.shape[3] != 3:
             raise ValueError(f"expected RGB uint8 image(s), got {arr.dtype} {arr.shape}")
         emb = self.model.embedder
-        patches = emb.preprocess(torch.from_numpy(arr).to(emb.device), rgb=True)
+        dev_arr = torch.from_numpy(arr).to(emb.device)
+        patches = self.model._g_pre(dev_arr) if arr.shape[0] == 1 else emb.preprocess(dev_arr, rgb=True)
         return LmxBatchFeature({"pixel_values": LmxPixelValues.wrap(patches, arr.shape[0])})
