@@ -97,8 +97,8 @@ def pmc_traffic_by_class():
             cls = "gemm/hbm-bound"      # f32-output (residual-stream) instantiations
         elif "gemm" in name:
             cls = "gemm/mfma-bound"
-        elif "attn_kernel<2, true, false, true" in name or "attn_kernel<2, false, false, true" in name:
-            cls = "attention/mfma-bound"  # the LDS-DMA instantiations: long flat sequences (Hiera's global blocks)
+        elif "attn_gp_kernel" in name or "attn_kernel<2, true, false, true" in name or "attn_kernel<2, false, false, true" in name:
+            cls = "attention/mfma-bound"  # the LDS-DMA kernels: long flat sequences (Hiera's global blocks)
         elif "attn" in name:
             cls = "attention/hbm-bound"
         elif "mlp_kernel" in name:  # (the summary truncates long mangled names from the left)

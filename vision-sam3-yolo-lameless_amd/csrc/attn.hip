@@ -1391,12 +1391,19 @@ __global__ __launch_bounds__(512, 1) void attn_spp_kernel(const lmx_attn_desc p,
             for (int r = 0; r < 4; ++r)
               if (kb * 16 + fg * 4 + r >= Tk_) sacc[qb][kb][r] = -INFINITY;
           }
-        float mx = fmaxf(fmaxf(sacc[qb][0][0], sacc[qb][0][1]), fmaxf(sacc[qb][0][2], sacc[qb][0][3]));
+        // row maximum: two v_max3_f32 chains (fmaxf on MFMA results costs a canonicalising v_max per operand), then the VALU
+        // cross-lane step of attn_gp_kernel instead of two ds_bpermute round trips
+        float ma = vmax3(sacc[qb][0][0], sacc[qb][0][1], sacc[qb][0][2]);
+        float mc = vmax3(sacc[qb][0][3], sacc[qb][1][0], sacc[qb][1][1]);
+        ma = vmax3(ma, sacc[qb][1][2], sacc[qb][1][3]);
 #pragma unroll
-        for (int kb = 1; kb < KB; ++kb)
-          mx = fmaxf(mx, fmaxf(fmaxf(sacc[qb][kb][0], sacc[qb][kb][1]), fmaxf(sacc[qb][kb][2], sacc[qb][kb][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int kb = 2; kb < KB; ++kb) {
+          if (kb & 1)
+            ma = vmax3(ma, sacc[qb][kb][0], sacc[qb][kb][1]), ma = vmax3(ma, sacc[qb][kb][2], sacc[qb][kb][3]);
+          else
+            mc = vmax3(mc, sacc[qb][kb][0], sacc[qb][kb][1]), mc = vmax3(mc, sacc[qb][kb][2], sacc[qb][kb][3]);
+        }
+        const float mx = row_max4(ma, mc);
         const float mb = mx * sl2;
         float rs = 0.f;
         const half2_t ones2 = {(half_t)1.0f, (half_t)1.0f};
@@ -1422,25 +1429,37 @@ __global__ __launch_bounds__(512, 1) void attn_spp_kernel(const lmx_attn_desc p,
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int db = 0; db < 4; ++db) oacc[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-      {  // V^T fragments (two transposing 8-byte reads each) through the same kind of ring
-        auto vread = [&](int i) {  // i = ks * 4 + db
+      {  // V^T fragments (two transposing 8-byte reads each) through the same kind of ring.  The reads are inline asm with counted
+        // waits of their own: through the builtin hipcc cannot tell them from the LDS-DMA writes in flight (the NEXT item's pieces
+        // this wave has just issued) and waits for vmcnt(0) in front of the first one — the prefetch then has to land before PV starts.
+        u32x2_t vlo[3], vhi[3];
+        auto vread = [&](int i, u32x2_t& lo, u32x2_t& hi) {  // i = ks * 4 + db
           const int ks = i >> 2, db = i & 3;
           const int chunk = db * 2 + (p4 >> 1);
           const int r0 = ks * 32 + fg * 4 + q4, r1 = ks == 6 ? r0 : r0 + 16;
-          const half4_t lo = lds_tr_read(&Vs[r0 * RW + ((chunk ^ (r0 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
-          const half4_t hi = lds_tr_read(&Vs[r1 * RW + ((chunk ^ (r1 & (CPR - 1))) << 3) + (p4 & 1) * 4]);
-          return half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const half_t*)&Vs[r0 * RW + ((chunk ^ (r0 & (CPR - 1))) << 3) + (p4 & 1) * 4];
+          const unsigned a1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const half_t*)&Vs[r1 * RW + ((chunk ^ (r1 & (CPR - 1))) << 3) + (p4 & 1) * 4];
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1) : "memory");
         };
-        half8_t vring[3];
-        vring[0] = vread(0);
-        vring[1] = vread(1);
+        vread(0, vlo[0], vhi[0]);
+        vread(1, vlo[1], vhi[1]);
 #pragma unroll
         for (int i = 0; i < 28; ++i) {
-          if (i + 2 < 28) vring[(i + 2) % 3] = vread(i + 2);
-          __builtin_amdgcn_sched_barrier(0);
+          if (i + 2 < 28) vread(i + 2, vlo[(i + 2) % 3], vhi[(i + 2) % 3]);
+          // fragment i has arrived once only the younger reads are outstanding (the registers are operands of the wait, so that no
+          // consumer can be scheduled in front of it)
+          if (i + 2 < 28)
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vlo[i % 3]), "+v"(vhi[i % 3])::"memory");
+          else if (i + 1 < 28)
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vlo[i % 3]), "+v"(vhi[i % 3])::"memory");
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[i % 3]), "+v"(vhi[i % 3])::"memory");
+          const u32x4_t w = {vlo[i % 3][0], vlo[i % 3][1], vhi[i % 3][0], vhi[i % 3][1]};
+          const half8_t vf = __builtin_bit_cast(half8_t, w);
           const int ks = i >> 2, db = i & 3;
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vring[i % 3], pf[qb][ks], oacc[qb][db], 0, 0, 0);
+          for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qb][ks], oacc[qb][db], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
