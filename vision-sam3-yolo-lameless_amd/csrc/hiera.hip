@@ -1,0 +1,272 @@
+// hiera.hip — the attention half of a Hiera block with 8 x 8-token windows as ONE kernel (stage 1 of Hiera-B+: D = 112, 2 heads of 56;
+// TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward: `hidden_states = residual + proj(attn(qkv(layer_norm1(x))))` with
+// window_partition / window_unpartition around the attention, :412-455).
+//
+// Why: at D = 112 the three launches it replaces — qkv GEMM (f16 rows in, 3D-wide f16 rows out), window attention (3D in, D out),
+// projection GEMM (+ f32 residual) — are each bound by HBM and move 896 + 896 + 1120 bytes per token between them, of which only the
+// LayerNorm rows in (224) and the f32 residual stream in and out (448 + 448) are algorithmic.
+//
+// How: a WAVE owns a window.  Its 64 tokens' LayerNorm rows are the register-resident operand of every product, all weights
+// (q | k | v | proj: 124 KB as f16 with each head padded to 64 rows) sit in LDS for the life of the workgroup, and nothing a wave
+// computes is ever seen by another wave: no barrier, no exchange buffer, no LDS write after the prologue.
+//     q^T[d][t] = Wq . X^T     k^T[d][t] = Wk . X^T      (A = weight rows from LDS, B = the window's rows)
+//     v[t][d]   = X . Wv^T                               (A = the window's rows — the same registers —, B = weight rows from LDS)
+//     S^T[key][query] = K . Q^T                          (A and B are the f16-rounded accumulators of k^T and q^T)
+//     P = exp2(S c - max c) in f16; column 63 of v is 1 (bias 1 on a zero weight row), so O^T row 63 is the softmax sum
+//     O^T[d][query] = V^T . P^T                          (A = rounded accumulators of v, B = P straight from S's accumulators)
+//     x^T[o][t] += Wo[:, head] . O^T / sum               (A = weight rows from LDS, B = rounded accumulators of O^T)
+// The accumulator layout of a 16 x 16 tile (lane (c, g) holds rows 4g..4g+3 of column c) is an operand layout of the next MFMA with
+// the contraction index permuted (k-slot 8g + 4h + i <-> row 16(2s + h) + 4g + i of k-step s; cdna guide section 3 "An accumulator
+// tile as the next MFMA's operand"): both operands of S and of PV come from accumulators and carry the same permutation; for the
+// projection the host stores Wo's columns in that order (lmx/sam.py pack_hiera_attn).
+// Rounding points are those of the unfused chain: q, k, v, P and the normalised attention output are rounded to f16, every sum is f32.
+// One wave per SIMD with the whole 512-register file (X 64, the projection's accumulators 112, q / k / v operands 96, S or O 64).
+#include "common.h"
+
+namespace {
+
+constexpr int D = 112, HEADS = 2, HP = 64, KS = 4;
+constexpr int ROWB = 256;                     // bytes per LDS weight row: 128 halfs, 16 chunks of 16 B, chunk c of row r at c ^ (r & 15)
+constexpr int NQKV = 3 * HEADS * HP;          // 384 rows: q h0 | q h1 | k h0 | k h1 | v h0 | v h1, 64 each (56 real)
+constexpr int W_BYTES = NQKV * ROWB;          // 96 KB
+constexpr int WO_BYTES = D * ROWB;            // 28 KB: [112 outputs][2 heads x 64 inputs, permuted]
+constexpr int B_OFF = W_BYTES + WO_BYTES;
+constexpr int SMEM = B_OFF + (NQKV + D) * 4;  // + biases (f32): 128 960 bytes
+
+__device__ __forceinline__ half8_t pack8(const f32x4 a, const f32x4 b) {
+  return half8_t{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+}
+__device__ __forceinline__ float hmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// maximum over the four 16-lane rows of a wave, in every row (scalar temporaries: a bit_cast of a vector element reads element 0)
+__device__ __forceinline__ float hrow_max4(float ma, float mc) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned u = __builtin_bit_cast(unsigned, fmaxf(ma, mc));
+  const u32x2 a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  const unsigned u1 = __builtin_bit_cast(unsigned, fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1)));
+  const u32x2 b = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+  const unsigned b0 = b[0], b1 = b[1];
+  return fmaxf(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
+}
+
+__global__ __launch_bounds__(256, 1) void hiera_attn8_kernel(const half_t* __restrict__ h, float* __restrict__ x, const int64_t ldx,
+                                                              const half_t* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                                              const half_t* __restrict__ wo, const float* __restrict__ bo, const int Gh,
+                                                              const int Gw, const int nwin, const float sl2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- prologue: all weights into LDS, swizzled
+  for (int i = tid; i < (NQKV + D) * 16; i += 256) {
+    const int r = i >> 4, c = i & 15;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(r < NQKV ? reinterpret_cast<const char*>(wqkv) + (int64_t)i * 16
+                                                             : reinterpret_cast<const char*>(wo) + (int64_t)(i - NQKV * 16) * 16);
+    *reinterpret_cast<u32x4*>(smem + r * ROWB + ((c ^ (r & 15)) << 4)) = v;
+  }
+  float* bias = reinterpret_cast<float*>(smem + B_OFF);
+  for (int i = tid; i < NQKV + D; i += 256) bias[i] = i < NQKV ? bqkv[i] : bo[i - NQKV];
+  __syncthreads();
+
+  // fragment of weight rows row0 .. row0 + 15, k-step ks: this lane's row is row0 + fr (row0 % 16 == 0), chunk 4 ks + fg
+  auto wfrag = [&](const int row0, const int ks) {
+    return *reinterpret_cast<const half8_t*>(smem + (row0 + fr) * ROWB + ((((ks << 2) + fg) ^ fr) << 4));
+  };
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int nWx = Gw >> 3, nWy = Gh >> 3;
+
+  for (int w = blockIdx.x * 4 + wave; w < nwin; w += gridDim.x * 4) {
+    const int img = w / (nWy * nWx), wi = w - img * (nWy * nWx);
+    const int wy = wi / nWx, wx = wi - wy * nWx;
+    // token t = 16 tb + fr of the window sits at window row 2 tb + (fr >> 3), column fr & 7
+    int64_t row[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) row[tb] = ((int64_t)img * Gh + wy * 8 + 2 * tb + (fr >> 3)) * Gw + wx * 8 + (fr & 7);
+
+    // X: the window's LayerNorm rows as MFMA operand fragments (features 32 ks + 8 fg .. + 7 of token fr; features >= 112 are zeros)
+    half8_t xn[4][KS];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d = ks * 32 + fg * 8;
+        const half8_t v = *reinterpret_cast<const half8_t*>(h + row[tb] * D + (d < D ? d : 0));
+        xn[tb][ks] = d < D ? v : zero8;
+      }
+    // the projection's accumulators start from the residual + bias: x is read once, long before its first use
+    f32x4 accp[7][4];
+#pragma unroll
+    for (int ob = 0; ob < 7; ++ob) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + NQKV + ob * 16 + fg * 4);
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) accp[ob][tb] = *reinterpret_cast<const f32x4*>(x + row[tb] * ldx + ob * 16 + fg * 4) + bv;
+    }
+
+#pragma unroll
+    for (int hh = 0; hh < HEADS; ++hh) {
+      half8_t qf[4][2], kf[4][2], vf[4][2];
+      // ---- q^T and k^T: [64 d][64 tokens] each; rounded to f16 they are the B (q) and A (k) operands of S
+#pragma unroll
+      for (int sec = 0; sec < 2; ++sec) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int r0 = sec * (HEADS * HP) + hh * HP;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + r0 + rb * 16 + fg * 4);
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[rb][tb] = bv;
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const half8_t a = wfrag(r0 + rb * 16, ks);
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[rb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[rb][tb], 0, 0, 0);
+          }
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const half8_t f = pack8(acc[2 * s][tb], acc[2 * s + 1][tb]);
+            if (sec == 0)
+              qf[tb][s] = f;
+            else
+              kf[tb][s] = f;
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // phase boundary: nothing moves across (live ranges stay those of the phases)
+      // ---- v: [64 tokens][64 d] (tokens are the MFMA rows here); rounded, it is the A operand of PV (rows d, k-slots keys)
+      {
+        const int r0 = 2 * (HEADS * HP) + hh * HP;
+        f32x4 acc[4][4];  // [token block][d block]
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const float b = bias[r0 + db * 16 + fr];
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[tb][db] = f32x4{b, b, b, b};
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const half8_t bw = wfrag(r0 + db * 16, ks);
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[tb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb][db], 0, 0, 0);
+          }
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) vf[db][s] = pack8(acc[2 * s][db], acc[2 * s + 1][db]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // phase boundary: nothing moves across (live ranges stay those of the phases)
+      // ---- S^T[key][query] = K . Q^T, softmax over the 64 keys of a query (16 in this lane, 4 lanes per query)
+      half8_t pf[4][2];
+      {
+        f32x4 sacc[4][4];  // [key block][query block]
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) {
+            sacc[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) sacc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][s], qf[qb][s], sacc[kb][qb], 0, 0, 0);
+          }
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+          float ma = hmax3(sacc[0][qb][0], sacc[0][qb][1], sacc[0][qb][2]);
+          float mc = hmax3(sacc[2][qb][0], sacc[2][qb][1], sacc[2][qb][2]);
+          ma = hmax3(ma, sacc[0][qb][3], sacc[1][qb][0]);
+          mc = hmax3(mc, sacc[2][qb][3], sacc[3][qb][0]);
+          ma = hmax3(ma, sacc[1][qb][1], sacc[1][qb][2]);
+          mc = hmax3(mc, sacc[3][qb][1], sacc[3][qb][2]);
+          ma = hmax3(ma, sacc[1][qb][3], sacc[3][qb][3]);
+          const float nmb = -(hrow_max4(ma, mc) * sl2);
+          f32x4 e[4];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[kb][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][qb][r], sl2, nmb));
+#pragma unroll
+          for (int s = 0; s < 2; ++s) pf[qb][s] = pack8(e[2 * s], e[2 * s + 1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // phase boundary: nothing moves across (live ranges stay those of the phases)
+      // ---- O^T[d][query] = V^T . P^T; row 63 is the softmax sum (v's column 63 is the constant 1); normalise, round
+      half8_t of[4][2];
+      {
+        f32x4 oacc[4][4];  // [d block][query block]
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) {
+            oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) oacc[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[db][s], pf[qb][s], oacc[db][qb], 0, 0, 0);
+          }
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+          const float l = __shfl(oacc[3][qb][3], 48 + fr, 64);  // O^T[63][query fr]: lane group 3, register 3 of d block 3
+          const float inv = 1.0f / l;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) of[qb][s] = pack8(oacc[2 * s][qb] * inv, oacc[2 * s + 1][qb] * inv);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // phase boundary: nothing moves across (live ranges stay those of the phases)
+      // ---- x^T[o][token] += Wo[:, head hh] . O^T   (Wo's columns of a head are stored in the operand's k-slot order; column 63 is zero)
+#pragma unroll
+      for (int ob = 0; ob < 7; ++ob)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const half8_t a = wfrag(NQKV + ob * 16, hh * 2 + s);
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) accp[ob][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, of[tb][s], accp[ob][tb], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- store the residual stream: lane (token fr, fg) holds features 16 ob + 4 fg .. + 3 of its four tokens
+#pragma unroll
+    for (int ob = 0; ob < 7; ++ob)
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) *reinterpret_cast<f32x4*>(x + row[tb] * ldx + ob * 16 + fg * 4) = accp[ob][tb];
+  }
+}
+
+}  // namespace
+
+// h f16 [rows, 112] (LayerNorm rows), x f32 [rows, ldx] updated in place, rows = n_img * Gh * Gw on a token grid whose sides are
+// multiples of 8.  wqkv_p f16 [384, 128], bqkv_p f32 [384], wo_p f16 [112, 128], bo f32 [112]: lmx/sam.py pack_hiera_attn.
+extern "C" int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const void* wqkv_p, const float* bqkv_p, const void* wo_p,
+                                 const float* bo, int n_img, int Gh, int Gw, int D_, int heads, float scale, lmx_stream_t stream) {
+  LMX_REQUIRE(h && x && wqkv_p && bqkv_p && wo_p && bo, "lmx_k_hiera_attn8: null pointer");
+  LMX_REQUIRE(D_ == D && heads == HEADS, "lmx_k_hiera_attn8: built for D = 112 with 2 heads, got D = %d heads = %d", D_, heads);
+  LMX_REQUIRE(n_img > 0 && Gh > 0 && Gw > 0 && Gh % 8 == 0 && Gw % 8 == 0, "lmx_k_hiera_attn8: token grid %d x %d is not whole 8 x 8 windows", Gh, Gw);
+  LMX_REQUIRE(ldx >= D && ldx % 4 == 0 && aligned16(h) && aligned16(x) && aligned16(wqkv_p) && aligned16(wo_p), "lmx_k_hiera_attn8: ldx / alignment");
+  const int64_t nwin = (int64_t)n_img * (Gh / 8) * (Gw / 8);
+  LMX_REQUIRE(nwin < (1ll << 31), "lmx_k_hiera_attn8: too many windows");
+  static bool attr_set = false;
+  if (!attr_set) {
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_attn8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    LMX_HIP(hipGetDevice(&dev));
+    LMX_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int64_t need = (nwin + 3) / 4;
+  const unsigned grid = (unsigned)(need < n_cu ? need : n_cu);
+  hipLaunchKernelGGL(hiera_attn8_kernel, dim3(grid), dim3(256), SMEM, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const half_t*>(h), x, ldx, reinterpret_cast<const half_t*>(wqkv_p), bqkv_p,
+                     reinterpret_cast<const half_t*>(wo_p), bo, Gh, Gw, (int)nwin, scale * 1.44269504088896340736f);
+  return lmx_launch_check("hiera_attn8_kernel");
+}

@@ -273,6 +273,27 @@ def ln_mlp(x, gamma, beta, w1, b1, w2, b2, eps, x16=None, next_ln=None):
     return x
 
 
+def hiera_attn8_ok(D, heads, win, Gh, Gw, q_stride):
+    """Shapes lmx_k_hiera_attn8 is built for: Hiera-B+ stage 1 (D 112, 2 heads of 56), whole 8 x 8 windows, no query pooling."""
+    return D == 112 and heads == 2 and win == 8 and not q_stride and Gh % 8 == 0 and Gw % 8 == 0 and os.environ.get("LMX_HIERA_ATTN8", "1") != "0"
+
+
+def hiera_attn8(h, x, packed, n_img, Gh, Gw, heads):
+    """x (f32 [rows, D], in place) += proj(window attention(qkv(h))) for 8 x 8-token windows (csrc/hiera.hip).  h f16 [rows, D]
+    contiguous; packed = (wqkv_p, bqkv_p, wo_p, bo) from lmx.sam.pack_hiera_attn."""
+    wq, bq, wo, bo = packed
+    dev = _dev(h, x, wq, bq, wo, bo)
+    rows, D, ldx = _rows(x, "hiera_attn8 x")
+    if x.dtype != torch.float32 or h.dtype != torch.float16 or tuple(h.shape) != (rows, D) or not h.is_contiguous() or rows != n_img * Gh * Gw:
+        raise LmxError("hiera_attn8: h must be contiguous float16 [n*Gh*Gw, D] and x float32 rows of the same count")
+    if tuple(wq.shape) != (3 * heads * 64, 128) or tuple(wo.shape) != (D, heads * 64) or wq.dtype != torch.float16 or wo.dtype != torch.float16 \
+            or not (wq.is_contiguous() and wo.is_contiguous()) or bq.numel() != 3 * heads * 64 or bo.numel() != D:
+        raise LmxError("hiera_attn8: packed operands have the wrong shapes (lmx.sam.pack_hiera_attn)")
+    check(_lib.load().lmx_k_hiera_attn8(_ptr(h), _ptr(x), ldx, _ptr(wq), _ptr(bq), _ptr(wo), _ptr(bo), n_img, Gh, Gw, D, heads,
+                                        float((D // heads) ** -0.5), _stream(dev)), "lmx_k_hiera_attn8")
+    return x
+
+
 def _attn_desc(q, k, v, out, B, H, Tq, Tk, hd, scale, window, pad_k, pad_v):
     d = AttnDesc()
     d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()

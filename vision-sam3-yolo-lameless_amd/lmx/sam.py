@@ -104,6 +104,36 @@ def sam_norm_lut():
     return ((u[None, :] - m[:, None]) / s[:, None]).astype(np.float32)
 
 
+def pack_hiera_attn(wqkv, bqkv, wo, bo, heads):
+    """Operands of lmx_k_hiera_attn8 (csrc/hiera.hip) from the block's torch-layout parameters: wqkv [3D, D], bqkv [3D], wo [D, D],
+    bo [D] (numpy, f32).  Returns (wqkv_p f16 [3*heads*64, 128], bqkv_p f32 [3*heads*64], wo_p f16 [D, heads*64], bo f32 [D]):
+    q | k | v sections with each head padded from D/heads to 64 rows and the inputs to 128 columns; v's row 63 of every head is zero
+    with bias 1 (the softmax sum then rides the PV product); the 64 columns of a head in wo_p are in MFMA k-slot order."""
+    D = wo.shape[0]
+    hd = D // heads
+    if hd > 63 or D > 128:
+        raise ValueError("pack_hiera_attn: head dim <= 63 and D <= 128")
+    wq = np.zeros((3 * heads * 64, 128), np.float32)
+    bq = np.zeros((3 * heads * 64,), np.float32)
+    for sec in range(3):
+        for hh in range(heads):
+            r0 = sec * heads * 64 + hh * 64
+            wq[r0:r0 + hd, :D] = wqkv[sec * D + hh * hd: sec * D + (hh + 1) * hd]
+            bq[r0:r0 + hd] = bqkv[sec * D + hh * hd: sec * D + (hh + 1) * hd]
+            if sec == 2:
+                bq[r0 + 63] = 1.0
+    wop = np.zeros((D, heads * 64), np.float32)
+    for hh in range(heads):
+        for s_ in range(2):
+            for g in range(4):
+                for hb in range(2):
+                    for i in range(4):
+                        d = 16 * (2 * s_ + hb) + 4 * g + i
+                        if d < hd:
+                            wop[:, 64 * hh + 32 * s_ + 8 * g + 4 * hb + i] = wo[:, hh * hd + d]
+    return wq.astype(np.float16), bq, wop.astype(np.float16), np.ascontiguousarray(bo, dtype=np.float32)
+
+
 class HieraEncoder:
     """Device-resident Hiera trunk + FPN.  ``encode(frames)`` -> dict(fpn=[3 NHWC f16 levels, high->low res],
     stages=[4 f32 stage outputs]).  Token grids are [n, H, W, C] row-major throughout (no partition copies)."""
@@ -149,6 +179,10 @@ class HieraEncoder:
                        w2=t16(sd[p + "mlp.proj_out.weight"]), bb2=t32(sd[p + "mlp.proj_out.bias"]))
             if dim != dim_out:
                 blk["wp"], blk["bp"] = t16(sd[p + "proj.weight"]), t32(sd[p + "proj.bias"])
+            if dim == dim_out == 112 and heads == 2 and win_ == 8 and not qs:  # stage 1 of Hiera-B+: one kernel per attention half
+                blk["attn8"] = tuple(torch.from_numpy(a).to(dev) for a in pack_hiera_attn(
+                    np.asarray(sd[p + "attn.qkv.weight"], np.float32), np.asarray(qkv_b, np.float32),
+                    np.asarray(sd[p + "attn.proj.weight"], np.float32), np.asarray(sd[p + "attn.proj.bias"], np.float32), heads))
             self.blocks.append(blk)
         n = len(cfg.dims) - 1
         self.neck = [(t16(sd[f"neck.convs.{n - i}.weight"][:, :, 0, 0]), t32(sd[f"neck.convs.{n - i}.bias"])) for i in range(n + 1)]
@@ -208,35 +242,10 @@ class HieraEncoder:
                 res = sc
             else:
                 res = x
-            Hq, Wq = H, W
-            if qs and K.pooled_gemm_ok(rows, D):
-                # pooled queries: the q third of the projection writes its 2 x 2 max-pool directly (a_mode 2), k and v come from
-                # a second launch on the same rows — the full-resolution q is neither written nor read back by a pooling pass
-                Hq, Wq = H // 2, W // 2
-                q = K.gemm(h, B["wqkv"][:D], bias=B["bqkv"][:D], pool_hw=(H, W))
-                kv = K.gemm(h, B["wqkv"][D:], bias=B["bqkv"][D:])
-                k, v = kv[:, :D], kv[:, D:]
+            if "attn8" in B and res is x and K.hiera_attn8_ok(D, heads, win, H, W, qs):
+                K.hiera_attn8(h, x, B["attn8"], n, H, W, heads)  # qkv -> window attention -> proj + residual in one launch (csrc/hiera.hip)
             else:
-                qkv = K.gemm(h, B["wqkv"], bias=B["bqkv"])
-                q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-                if qs:
-                    Hq, Wq = H // 2, W // 2
-                    qp = torch.empty((n, Hq, Wq, D), dtype=torch.float16, device=dev)
-                    K.maxpool2(qkv.view(n, H, W, 3 * D)[..., :D], qp)
-                    q = qp.view(-1, D)
-            a = torch.empty((n * Hq * Wq, D), dtype=torch.float16, device=dev)
-            if win > 0:
-                nW = -(-H // win) * -(-W // win)
-                wq = win // 2 if qs else win
-                K.attention(q, k, v, a, n * nW, heads, wq * wq, win * win, hd, hd ** -0.5,
-                            window=dict(Gh=H, Gw=W, ws=win, q_stride=2 if qs else 1),
-                            pad_k=B["padkv"][D:2 * D], pad_v=B["padkv"][2 * D:])
-            else:
-                K.attention(q, k, v, a, n, heads, Hq * Wq, H * W, hd, hd ** -0.5)
-            H, W = Hq, Wq
-            xo = torch.empty((n * H * W, D), dtype=torch.float32, device=dev) if res is not x else x
-            K.gemm(a, B["wo"], bias=B["bo"], res=res, out=xo)
-            x = xo
+                x, H, W = self._attention_half(B, h, x, res, n, H, W)
             x16 = None
             if D in K.FUSED_MLP_WIDTHS and self.fused_mlp:
                 if i in stage_ends:  # the FPN's lateral convolution reads this stage output as f16: written here, not cast later
@@ -256,6 +265,41 @@ class HieraEncoder:
                 if i != len(self.blocks) - 1 and self.blocks[i + 1]["dim"] == self.blocks[i + 1]["dim_out"]:
                     x = x.clone()  # the stage output is kept; a same-width next block would update it in place
         return stages, stages16  # stages16: f16 copies of the stage outputs where the stage's last kernel wrote one (else None)
+
+    def _attention_half(self, B, h, x, res, n, H, W):
+        """qkv GEMM -> [Q-pool] -> attention -> proj GEMM + residual as separate launches; returns (x, H, W) after the block's pooling."""
+        D, heads, win, qs = B["dim_out"], B["heads"], B["win"], B["qs"]
+        hd = D // heads
+        rows = n * H * W
+        dev = h.device
+        Hq, Wq = H, W
+        if qs and K.pooled_gemm_ok(rows, D):
+            # pooled queries: the q third of the projection writes its 2 x 2 max-pool directly (a_mode 2), k and v come from
+            # a second launch on the same rows — the full-resolution q is neither written nor read back by a pooling pass
+            Hq, Wq = H // 2, W // 2
+            q = K.gemm(h, B["wqkv"][:D], bias=B["bqkv"][:D], pool_hw=(H, W))
+            kv = K.gemm(h, B["wqkv"][D:], bias=B["bqkv"][D:])
+            k, v = kv[:, :D], kv[:, D:]
+        else:
+            qkv = K.gemm(h, B["wqkv"], bias=B["bqkv"])
+            q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+            if qs:
+                Hq, Wq = H // 2, W // 2
+                qp = torch.empty((n, Hq, Wq, D), dtype=torch.float16, device=dev)
+                K.maxpool2(qkv.view(n, H, W, 3 * D)[..., :D], qp)
+                q = qp.view(-1, D)
+        a = torch.empty((n * Hq * Wq, D), dtype=torch.float16, device=dev)
+        if win > 0:
+            nW = -(-H // win) * -(-W // win)
+            wq = win // 2 if qs else win
+            K.attention(q, k, v, a, n * nW, heads, wq * wq, win * win, hd, hd ** -0.5,
+                        window=dict(Gh=H, Gw=W, ws=win, q_stride=2 if qs else 1),
+                        pad_k=B["padkv"][D:2 * D], pad_v=B["padkv"][2 * D:])
+        else:
+            K.attention(q, k, v, a, n, heads, Hq * Wq, H * W, hd, hd ** -0.5)
+        xo = torch.empty((n * Hq * Wq, D), dtype=torch.float32, device=dev) if res is not x else x
+        K.gemm(a, B["wo"], bias=B["bo"], res=res, out=xo)
+        return xo, Hq, Wq
 
     def fpn(self, stages, stages16=None):
         cfg = self.cfg
