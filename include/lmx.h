@@ -102,18 +102,21 @@ int lmx_k_layernorm(const void* x, int in_dtype, int64_t ldx, const float* gamma
                     void* y, int out_dtype, int64_t ldy, int rows, int D, float eps, int act, lmx_stream_t stream);
 /* (act = LMX_ACT_NONE or LMX_ACT_GELU applied after the affine: the SAM decoder's LayerNorm2d -> GELU, TF sam :523) */
 
-/* ---- K8-K10 + K14 for Hiera's 8 x 8-token windows: x += proj(window_attention(qkv(h))) as one kernel -------------------------
+/* ---- K11 + K8-K10 + K14 for Hiera's 8 x 8-token windows: x += proj(window_attention(qkv(layer_norm1(x)))) as one kernel ---------
  * Replaces, for the blocks of Hiera-B+ stage 1 (D = 112, 2 heads; TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward,
- * Sam2MultiScaleAttention :350-409 with window_partition / window_unpartition :412-455), the three launches qkv GEMM -> window
- * attention -> projection GEMM (+ residual) and their 3D- and D-wide f16 intermediates: per token it reads the LayerNorm row (2D
- * bytes) and the f32 stream (4D) and writes the stream (4D).  h f16 [rows, D] contiguous = layer_norm1(x); x f32 [rows, ldx]
- * updated in place; rows = n_img * Gh * Gw, Gh and Gw multiples of 8 (no padded windows).  Packed operands (lmx/sam.py
- * pack_hiera_attn): wqkv_p f16 [3*heads*64, 128] — sections q | k | v, each head padded from 56 to 64 rows, input features padded
- * to 128 columns; v's row 63 of every head is zero with bias 1 (the softmax sum rides the PV product) — bqkv_p f32 [3*heads*64],
- * wo_p f16 [D, heads*64] with the 64 columns of a head in MFMA k-slot order (position 32s + 8g + 4h + i holds input 16(2s+h) + 4g + i),
- * bo f32 [D].  scale = head_dim ** -0.5.  Rounding points as in the unfused chain: q, k, v, P, attention output f16; sums f32. */
-int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const void* wqkv_p, const float* bqkv_p, const void* wo_p,
-                      const float* bo, int n_img, int Gh, int Gw, int D, int heads, float scale, lmx_stream_t stream);
+ * Sam2MultiScaleAttention :350-409 with window_partition / window_unpartition :412-455), the four launches LayerNorm -> qkv GEMM ->
+ * window attention -> projection GEMM (+ residual) and their f16 intermediates: per token it reads the f32 stream (4D bytes) and
+ * writes it (4D).  x f32 [rows, ldx] updated in place; rows = n_img * Gh * Gw, Gh and Gw multiples of 8 (no padded windows).
+ * h = NULL: the kernel normalises x itself (gamma, beta f32 [D], eps: layer_norm1); h = f16 [rows, D] contiguous: layer_norm1(x) as
+ * written by the previous block's lmx_k_ln_mlp (h_next), read instead (+ 2D bytes per token; wqkv_p's columns then in natural order:
+ * cheaper when the rows exist anyway, because the kernel's first products then do not wait for the f32 rows).  Packed operands (lmx/sam.py pack_hiera_attn): wqkv_p f16 [3*heads*64, 128] — sections
+ * q | k | v, each head padded from 56 to 64 rows; v's row 63 of every head is zero with bias 1 (the softmax sum rides the PV
+ * product); columns in MFMA k-slot order (position 32s + 8g + 4h + i holds input feature 16(2s+h) + 4g + i, zeros past D) —
+ * bqkv_p f32 [3*heads*64], wo_p f16 [D, heads*64] with the 64 columns of a head in the same order, bo f32 [D].
+ * scale = head_dim ** -0.5.  Rounding points as in the unfused chain: LayerNorm output, q, k, v, P, attention output f16; sums f32. */
+int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* wqkv_p,
+                      const float* bqkv_p, const void* wo_p, const float* bo, int n_img, int Gh, int Gw, int D, int heads, float scale,
+                      lmx_stream_t stream);
 
 /* ---- K11+K12 for narrow widths: x += fc2(gelu(fc1(LayerNorm(x)))) without the 4D-wide hidden tensor ever reaching HBM ----
  * Replaces `hidden_states + self.mlp(self.layer_norm2(hidden_states))` of the Hiera blocks whose width is 112 or 224

@@ -480,41 +480,48 @@ def test_conv3x3_split_k_partials(cuda, n, H, W, cin, cout, stride, S):
     assert float((hi + lo - v).abs().max()) <= 2e-6 * float(v.abs().max()) + 1e-7
 
 
+@pytest.mark.parametrize("ln_inside", [True, False])
 @pytest.mark.parametrize("n,Gh,Gw", [(1, 8, 8), (2, 16, 24), (3, 64, 64)])
-def test_hiera_attn8_fused_block(cuda, n, Gh, Gw):
-    """lmx_k_hiera_attn8 (csrc/hiera.hip): x += proj(window attention(qkv(h))) for 8 x 8-token windows in one launch, against (a) the
-    fp32 definition (TF sam2 Sam2MultiScaleAttention over window_partition'ed tokens) on the f16-rounded operands and (b) the three
-    launches it replaces (same rounding points; the f32 sums run in a different order)."""
+def test_hiera_attn8_fused_block(cuda, n, Gh, Gw, ln_inside):
+    """lmx_k_hiera_attn8 (csrc/hiera.hip): x += proj(window attention(qkv(layer_norm1(x)))) for 8 x 8-token windows in one launch,
+    against (a) the fp32 definition (TF sam2 Sam2MultiScaleBlock / Sam2MultiScaleAttention over window_partition'ed tokens) with the
+    f16-rounded weights and (b) the four launches it replaces (same rounding points; the f32 sums run in a different order); in both
+    forms: layer_norm1 inside the kernel, or its f16 rows handed in."""
     from lmx import kernels as Kk
     from lmx import sam
 
-    D, heads, hd = 112, 2, 56
+    D, heads, hd, eps = 112, 2, 56, 1e-6
     rows = n * Gh * Gw
-    h = _rand((rows, D), 71, 1.0).half()
-    x = _rand((rows, D), 72, 1.0)
+    x = _rand((rows, D), 72, 1.0) + 0.3
+    gam, bet = 1.0 + _rand((D,), 77, 0.2), _rand((D,), 78, 0.2)
     wqkv = (_rand((3 * D, D), 73, 1.0) * D ** -0.5).half().float()
     bqkv = _rand((3 * D,), 74, 0.2)
     wo = (_rand((D, D), 75, 1.0) * D ** -0.5).half().float()
     bo = _rand((D,), 76, 0.2)
     # (a) fp32 definition
-    qkv = h.float() @ wqkv.t() + bqkv
+    h = torch.nn.functional.layer_norm(x, (D,), gam, bet, eps)
+    qkv = h @ wqkv.t() + bqkv
     t = qkv.view(n, Gh // 8, 8, Gw // 8, 8, 3, heads, hd).permute(5, 0, 1, 3, 6, 2, 4, 7).reshape(3, -1, heads, 64, hd)
     att = torch.softmax(t[0] @ t[1].transpose(-1, -2) * hd ** -0.5, -1) @ t[2]  # [windows, heads, 64, hd]
     att = att.view(n, Gh // 8, Gw // 8, heads, 8, 8, hd).permute(0, 1, 4, 2, 5, 3, 6).reshape(rows, D)
     ref = x + att @ wo.t() + bo
     # device
-    packed = tuple(torch.from_numpy(a).to(cuda) for a in sam.pack_hiera_attn(wqkv.numpy(), bqkv.numpy(), wo.numpy(), bo.numpy(), heads))
+    packed = tuple(torch.from_numpy(a).to(cuda) for a in sam.pack_hiera_attn(wqkv.numpy(), bqkv.numpy(), wo.numpy(), bo.numpy(), heads,
+                                                                             ln_inside=ln_inside))
     xd = x.to(cuda)
-    Kk.hiera_attn8(h.to(cuda), xd, packed, n, Gh, Gw, heads)
+    if ln_inside:
+        Kk.hiera_attn8(xd, packed, n, Gh, Gw, heads, ln=(gam.to(cuda), bet.to(cuda), eps))
+    else:
+        Kk.hiera_attn8(xd, packed, n, Gh, Gw, heads, h=Kk.layernorm(xd, gam.to(cuda), bet.to(cuda), eps))
     _close(xd, ref, 4e-3, 4e-3, f"hiera_attn8 n{n} {Gh}x{Gw} vs fp32")
     # (b) the unfused launches
-    hd_, w16, wo16 = h.to(cuda), wqkv.half().to(cuda), wo.half().to(cuda)
-    q3 = Kk.gemm(hd_, w16, bias=bqkv.to(cuda))
+    xu = x.to(cuda)
+    hd_ = Kk.layernorm(xu, gam.to(cuda), bet.to(cuda), eps)
+    q3 = Kk.gemm(hd_, wqkv.half().to(cuda), bias=bqkv.to(cuda))
     a = torch.empty((rows, D), dtype=torch.float16, device=cuda)
     Kk.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], a, n * (Gh // 8) * (Gw // 8), heads, 64, 64, hd, hd ** -0.5,
                  window=dict(Gh=Gh, Gw=Gw, ws=8, q_stride=1), pad_k=q3[0, D:2 * D].contiguous(), pad_v=q3[0, 2 * D:].contiguous())
-    xu = x.to(cuda)
-    Kk.gemm(a, wo16, bias=bo.to(cuda), res=xu, out=xu)
+    Kk.gemm(a, wo.half().to(cuda), bias=bo.to(cuda), res=xu, out=xu)
     d = (xd - xu).abs().max().item()
     print(f"hiera_attn8 n{n} {Gh}x{Gw}: max |fused - unfused| {d:.3e}, max |fused - fp32| {(xd.cpu() - ref).abs().max().item():.3e}, "
           f"max |unfused - fp32| {(xu.cpu() - ref).abs().max().item():.3e}")

@@ -1,4 +1,4 @@
-"""lmx_k_hiera_attn8 (csrc/hiera.hip) against the three launches it replaces at Hiera-B+ stage 1's shape in the benched step:
+"""lmx_k_hiera_attn8 (csrc/hiera.hip) against the four launches it replaces at Hiera-B+ stage 1's shape in the benched step:
 30 frames x 256 x 256 tokens, D = 112, 2 heads, 8 x 8 windows."""
 import os
 import sys
@@ -16,18 +16,20 @@ D, heads, hd = 112, 2, 56
 for n, G in ((30, 256), (10, 256)):
     rows = n * G * G
     g = torch.Generator().manual_seed(5)
-    h = torch.randn((rows, D), generator=g).half().to(dev)
     x = torch.randn((rows, D), generator=g).to(dev)
+    gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
     wqkv = (torch.randn((3 * D, D), generator=g) * D ** -0.5).half().float()
     bqkv = torch.randn((3 * D,), generator=g) * 0.2
     wo = (torch.randn((D, D), generator=g) * D ** -0.5).half().float()
     bo = torch.randn((D,), generator=g) * 0.2
-    packed = tuple(torch.from_numpy(a).to(dev) for a in sam.pack_hiera_attn(wqkv.numpy(), bqkv.numpy(), wo.numpy(), bo.numpy(), heads))
+    packed = tuple(torch.from_numpy(a).to(dev) for a in sam.pack_hiera_attn(wqkv.numpy(), bqkv.numpy(), wo.numpy(), bo.numpy(), heads, ln_inside=True))
+    packed_h = tuple(torch.from_numpy(a).to(dev) for a in sam.pack_hiera_attn(wqkv.numpy(), bqkv.numpy(), wo.numpy(), bo.numpy(), heads))
     w16, wo16, bq, bod = wqkv.half().to(dev), wo.half().to(dev), bqkv.to(dev), bo.to(dev)
     a = torch.empty((rows, D), dtype=torch.float16, device=dev)
     pk, pv = torch.zeros(D, dtype=torch.float16, device=dev), torch.zeros(D, dtype=torch.float16, device=dev)
 
     def unfused():
+        h = K.layernorm(x, gam, bet, 1e-6)
         q3 = K.gemm(h, w16, bias=bq)
         K.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], a, n * (G // 8) ** 2, heads, 64, 64, hd, hd ** -0.5,
                     window=dict(Gh=G, Gw=G, ws=8, q_stride=1), pad_k=pk, pad_v=pv)
@@ -35,6 +37,11 @@ for n, G in ((30, 256), (10, 256)):
 
     t_u = timeit(unfused, iters=5)
     x.normal_()
-    t_f = timeit(lambda: K.hiera_attn8(h, x, packed, n, G, G, heads), iters=5)
-    print(f"{n} frames: unfused (qkv GEMM + window attention + proj GEMM) {t_u * 1e3:.0f} us, fused {t_f * 1e3:.0f} us "
-          f"({rows * 1120 / t_f / 1e9:.2f} TB/s algorithmic, {rows / 64 * 624 * 16384 / t_f / 1e9:.0f} TFLOP/s issued)", flush=True)
+    t_f = timeit(lambda: K.hiera_attn8(x, packed, n, G, G, heads, ln=(gam, bet, 1e-6)), iters=5)
+    x.normal_()
+    hh = K.layernorm(x, gam, bet, 1e-6)
+    t_l = timeit(lambda: K.layernorm(x, gam, bet, 1e-6), iters=5)
+    t_h = timeit(lambda: K.hiera_attn8(x, packed_h, n, G, G, heads, h=hh), iters=5)
+    print(f"{n} frames: LayerNorm launch {t_l * 1e3:.0f} us; fused on precomputed LayerNorm rows {t_h * 1e3:.0f} us", flush=True)
+    print(f"{n} frames: unfused (LayerNorm + qkv GEMM + window attention + proj GEMM) {t_u * 1e3:.0f} us, fused incl. LayerNorm {t_f * 1e3:.0f} us "
+          f"({rows * 896 / t_f / 1e9:.2f} TB/s algorithmic, {rows / 64 * 624 * 16384 / t_f / 1e9:.0f} TFLOP/s issued)", flush=True)

@@ -2,11 +2,13 @@
 // TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward: `hidden_states = residual + proj(attn(qkv(layer_norm1(x))))` with
 // window_partition / window_unpartition around the attention, :412-455).
 //
-// Why: at D = 112 the three launches it replaces — qkv GEMM (f16 rows in, 3D-wide f16 rows out), window attention (3D in, D out),
-// projection GEMM (+ f32 residual) — are each bound by HBM and move 896 + 896 + 1120 bytes per token between them, of which only the
-// LayerNorm rows in (224) and the f32 residual stream in and out (448 + 448) are algorithmic.
+// Why: at D = 112 the four launches it replaces — LayerNorm (f32 rows in, f16 rows out), qkv GEMM (f16 rows in, 3D-wide f16 rows
+// out), window attention (3D in, D out), projection GEMM (+ f32 residual) — are each bound by HBM and move 672 + 896 + 896 + 1120
+// bytes per token between them, of which only the f32 residual stream in and out (448 + 448) is algorithmic.
 //
-// How: a WAVE owns a window.  Its 64 tokens' LayerNorm rows are the register-resident operand of every product, all weights
+// How: a WAVE owns a window.  It reads the window's 64 f32 rows once — they are both the LayerNorm's input and the residual —,
+// normalises them in registers (a token's 112 features sit in four lanes), and the f16-rounded result is the register-resident
+// operand of every product; all weights
 // (q | k | v | proj: 124 KB as f16 with each head padded to 64 rows) sit in LDS for the life of the workgroup, and nothing a wave
 // computes is ever seen by another wave: no barrier, no exchange buffer, no LDS write after the prologue.
 //     q^T[d][t] = Wq . X^T     k^T[d][t] = Wk . X^T      (A = weight rows from LDS, B = the window's rows)
@@ -18,8 +20,13 @@
 // The accumulator layout of a 16 x 16 tile (lane (c, g) holds rows 4g..4g+3 of column c) is an operand layout of the next MFMA with
 // the contraction index permuted (k-slot 8g + 4h + i <-> row 16(2s + h) + 4g + i of k-step s; cdna guide section 3 "An accumulator
 // tile as the next MFMA's operand"): both operands of S and of PV come from accumulators and carry the same permutation; for the
-// projection the host stores Wo's columns in that order (lmx/sam.py pack_hiera_attn).
-// Rounding points are those of the unfused chain: q, k, v, P and the normalised attention output are rounded to f16, every sum is f32.
+// projection the host stores Wo's columns in that order, and — because the f32 rows are read in the accumulator layout of the
+// projection they will be added to — the columns of Wq, Wk, Wv as well (lmx/sam.py pack_hiera_attn).
+// Rounding points are those of the unfused chain: LayerNorm output, q, k, v, P and the normalised attention output are rounded to
+// f16, every sum is f32; the LayerNorm has the arithmetic form of norm.hip (mean, centred sum of squares, 1 / sqrtf(var + eps)).
+// (Tried on top and slower: weight fragments through a three-deep register ring with sched_barriers, 531 -> 699 us — hipcc's own
+// order, the next read issued behind four MFMAs that are still executing, hides most of the LDS latency —, and requesting the next
+// window's rows early, 799 us with spills.)
 // One wave per SIMD with the whole 512-register file (X 64, the projection's accumulators 112, q / k / v operands 96, S or O 64).
 #include "common.h"
 
@@ -31,7 +38,7 @@ constexpr int NQKV = 3 * HEADS * HP;          // 384 rows: q h0 | q h1 | k h0 | 
 constexpr int W_BYTES = NQKV * ROWB;          // 96 KB
 constexpr int WO_BYTES = D * ROWB;            // 28 KB: [112 outputs][2 heads x 64 inputs, permuted]
 constexpr int B_OFF = W_BYTES + WO_BYTES;
-constexpr int SMEM = B_OFF + (NQKV + D) * 4;  // + biases (f32): 128 960 bytes
+constexpr int SMEM = B_OFF + (NQKV + 3 * D) * 4;  // + biases, LayerNorm gamma and beta (f32): 129 856 bytes
 
 __device__ __forceinline__ half8_t pack8(const f32x4 a, const f32x4 b) {
   return half8_t{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
@@ -53,7 +60,21 @@ __device__ __forceinline__ float hrow_max4(float ma, float mc) {
   return fmaxf(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
 }
 
+__device__ __forceinline__ float hrow_sum4(float v) {  // sum over the four 16-lane rows of a wave, in every row
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const u32x2 a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1));
+  const u32x2 b = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+  const unsigned b0 = b[0], b1 = b[1];
+  return __builtin_bit_cast(float, b0) + __builtin_bit_cast(float, b1);
+}
+
+// INLN: layer_norm1 runs in here (h unused); otherwise h holds its f16 rows (written by the previous block's fused MLP, csrc/mlp.hip)
+template <bool INLN>
 __global__ __launch_bounds__(256, 1) void hiera_attn8_kernel(const half_t* __restrict__ h, float* __restrict__ x, const int64_t ldx,
+                                                              const float* __restrict__ gam, const float* __restrict__ bet, const float eps,
                                                               const half_t* __restrict__ wqkv, const float* __restrict__ bqkv,
                                                               const half_t* __restrict__ wo, const float* __restrict__ bo, const int Gh,
                                                               const int Gw, const int nwin, const float sl2) {
@@ -70,14 +91,14 @@ __global__ __launch_bounds__(256, 1) void hiera_attn8_kernel(const half_t* __res
     *reinterpret_cast<u32x4*>(smem + r * ROWB + ((c ^ (r & 15)) << 4)) = v;
   }
   float* bias = reinterpret_cast<float*>(smem + B_OFF);
-  for (int i = tid; i < NQKV + D; i += 256) bias[i] = i < NQKV ? bqkv[i] : bo[i - NQKV];
+  for (int i = tid; i < NQKV + (INLN ? 3 : 1) * D; i += 256)
+    bias[i] = i < NQKV ? bqkv[i] : (i < NQKV + D ? bo[i - NQKV] : (i < NQKV + 2 * D ? gam[i - NQKV - D] : bet[i - NQKV - 2 * D]));
   __syncthreads();
 
   // fragment of weight rows row0 .. row0 + 15, k-step ks: this lane's row is row0 + fr (row0 % 16 == 0), chunk 4 ks + fg
   auto wfrag = [&](const int row0, const int ks) {
     return *reinterpret_cast<const half8_t*>(smem + (row0 + fr) * ROWB + ((((ks << 2) + fg) ^ fr) << 4));
   };
-  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   const int nWx = Gw >> 3, nWy = Gh >> 3;
 
   for (int w = blockIdx.x * 4 + wave; w < nwin; w += gridDim.x * 4) {
@@ -88,24 +109,66 @@ __global__ __launch_bounds__(256, 1) void hiera_attn8_kernel(const half_t* __res
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb) row[tb] = ((int64_t)img * Gh + wy * 8 + 2 * tb + (fr >> 3)) * Gw + wx * 8 + (fr & 7);
 
-    // X: the window's LayerNorm rows as MFMA operand fragments (features 32 ks + 8 fg .. + 7 of token fr; features >= 112 are zeros)
-    half8_t xn[4][KS];
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int d = ks * 32 + fg * 8;
-        const half8_t v = *reinterpret_cast<const half8_t*>(h + row[tb] * D + (d < D ? d : 0));
-        xn[tb][ks] = d < D ? v : zero8;
-      }
-    // the projection's accumulators start from the residual + bias: x is read once, long before its first use
+    // the window's f32 rows in the projection's accumulator layout: lane (token fr, fg) holds features 16 ob + 4 fg .. + 3.  They are
+    // the residual (read once; in the h form long before its first use) and, with INLN, the LayerNorm's input
     f32x4 accp[7][4];
+#pragma unroll
+    for (int ob = 0; ob < 7; ++ob)
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) accp[ob][tb] = *reinterpret_cast<const f32x4*>(x + row[tb] * ldx + ob * 16 + fg * 4);
+    half8_t xn[4][KS];
+    if constexpr (!INLN) {
+      // X: the window's LayerNorm rows as MFMA operand fragments (features 32 ks + 8 fg .. + 7 of token fr; features >= 112 are zeros)
+      const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int d = ks * 32 + fg * 8;
+          const half8_t v = *reinterpret_cast<const half8_t*>(h + row[tb] * D + (d < D ? d : 0));
+          xn[tb][ks] = d < D ? v : zero8;
+        }
+    } else {
+      // LayerNorm (layer_norm1) in registers; rounded to f16 it is X: k-slot 8 fg + 4 hb + i of k-step ks is feature
+      // 16 (2 ks + hb) + 4 fg + i (the weights' columns are stored in that order for this form); the eighth block does not exist: zeros
+      float mean[4], rstd[4];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        float sm = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < 7; ++ob) sm += (accp[ob][tb][0] + accp[ob][tb][1]) + (accp[ob][tb][2] + accp[ob][tb][3]);
+        mean[tb] = hrow_sum4(sm) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < 7; ++ob) {
+          const f32x4 dl = accp[ob][tb] - mean[tb];
+          sq += (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]);
+        }
+        rstd[tb] = 1.0f / sqrtf(hrow_sum4(sq) / (float)D + eps);
+      }
+      f32x4 nrm[8][4];
+#pragma unroll
+      for (int ob = 0; ob < 7; ++ob) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(bias + NQKV + D + ob * 16 + fg * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + NQKV + 2 * D + ob * 16 + fg * 4);
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) nrm[ob][tb] = (accp[ob][tb] - mean[tb]) * rstd[tb] * g + b;
+      }
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) nrm[7][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xn[tb][ks] = pack8(nrm[2 * ks][tb], nrm[2 * ks + 1][tb]);
+    }
+    // the projection's accumulators start from the residual + bias
 #pragma unroll
     for (int ob = 0; ob < 7; ++ob) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + NQKV + ob * 16 + fg * 4);
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb) accp[ob][tb] = *reinterpret_cast<const f32x4*>(x + row[tb] * ldx + ob * 16 + fg * 4) + bv;
+      for (int tb = 0; tb < 4; ++tb) accp[ob][tb] += bv;
     }
+    __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
     for (int hh = 0; hh < HEADS; ++hh) {
@@ -240,19 +303,22 @@ __global__ __launch_bounds__(256, 1) void hiera_attn8_kernel(const half_t* __res
 
 }  // namespace
 
-// h f16 [rows, 112] (LayerNorm rows), x f32 [rows, ldx] updated in place, rows = n_img * Gh * Gw on a token grid whose sides are
-// multiples of 8.  wqkv_p f16 [384, 128], bqkv_p f32 [384], wo_p f16 [112, 128], bo f32 [112]: lmx/sam.py pack_hiera_attn.
-extern "C" int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const void* wqkv_p, const float* bqkv_p, const void* wo_p,
-                                 const float* bo, int n_img, int Gh, int Gw, int D_, int heads, float scale, lmx_stream_t stream) {
-  LMX_REQUIRE(h && x && wqkv_p && bqkv_p && wo_p && bo, "lmx_k_hiera_attn8: null pointer");
+// x f32 [rows, ldx] updated in place, rows = n_img * Gh * Gw on a token grid whose sides are multiples of 8.  h f16 [rows, 112] =
+// layer_norm1(x), or NULL: the kernel then normalises x itself with gamma, beta f32 [112], eps (and wqkv_p's columns are in k-slot
+// order).  wqkv_p f16 [384, 128], bqkv_p f32 [384], wo_p f16 [112, 128], bo f32 [112]: lmx/sam.py pack_hiera_attn.
+extern "C" int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* wqkv_p,
+                                 const float* bqkv_p, const void* wo_p, const float* bo, int n_img, int Gh, int Gw, int D_, int heads,
+                                 float scale, lmx_stream_t stream) {
+  LMX_REQUIRE(x && (h || (gamma && beta)) && wqkv_p && bqkv_p && wo_p && bo, "lmx_k_hiera_attn8: null pointer");
   LMX_REQUIRE(D_ == D && heads == HEADS, "lmx_k_hiera_attn8: built for D = 112 with 2 heads, got D = %d heads = %d", D_, heads);
   LMX_REQUIRE(n_img > 0 && Gh > 0 && Gw > 0 && Gh % 8 == 0 && Gw % 8 == 0, "lmx_k_hiera_attn8: token grid %d x %d is not whole 8 x 8 windows", Gh, Gw);
-  LMX_REQUIRE(ldx >= D && ldx % 4 == 0 && aligned16(h) && aligned16(x) && aligned16(wqkv_p) && aligned16(wo_p), "lmx_k_hiera_attn8: ldx / alignment");
+  LMX_REQUIRE(ldx >= D && ldx % 4 == 0 && aligned16(x) && aligned16(h) && aligned16(wqkv_p) && aligned16(wo_p), "lmx_k_hiera_attn8: ldx / alignment");
   const int64_t nwin = (int64_t)n_img * (Gh / 8) * (Gw / 8);
   LMX_REQUIRE(nwin < (1ll << 31), "lmx_k_hiera_attn8: too many windows");
   static bool attr_set = false;
   if (!attr_set) {
-    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_attn8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_attn8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_attn8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set = true;
   }
   static int n_cu = 0;
@@ -265,8 +331,13 @@ extern "C" int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const voi
   }
   const int64_t need = (nwin + 3) / 4;
   const unsigned grid = (unsigned)(need < n_cu ? need : n_cu);
-  hipLaunchKernelGGL(hiera_attn8_kernel, dim3(grid), dim3(256), SMEM, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const half_t*>(h), x, ldx, reinterpret_cast<const half_t*>(wqkv_p), bqkv_p,
-                     reinterpret_cast<const half_t*>(wo_p), bo, Gh, Gw, (int)nwin, scale * 1.44269504088896340736f);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const half_t* hp = reinterpret_cast<const half_t*>(h);
+  const half_t *wq = reinterpret_cast<const half_t*>(wqkv_p), *wop = reinterpret_cast<const half_t*>(wo_p);
+  const float sl2 = scale * 1.44269504088896340736f;
+  if (h)
+    hipLaunchKernelGGL(hiera_attn8_kernel<false>, dim3(grid), dim3(256), SMEM, st, hp, x, ldx, gamma, beta, eps, wq, bqkv_p, wop, bo, Gh, Gw, (int)nwin, sl2);
+  else
+    hipLaunchKernelGGL(hiera_attn8_kernel<true>, dim3(grid), dim3(256), SMEM, st, hp, x, ldx, gamma, beta, eps, wq, bqkv_p, wop, bo, Gh, Gw, (int)nwin, sl2);
   return lmx_launch_check("hiera_attn8_kernel");
 }

@@ -278,19 +278,27 @@ def hiera_attn8_ok(D, heads, win, Gh, Gw, q_stride):
     return D == 112 and heads == 2 and win == 8 and not q_stride and Gh % 8 == 0 and Gw % 8 == 0 and os.environ.get("LMX_HIERA_ATTN8", "1") != "0"
 
 
-def hiera_attn8(h, x, packed, n_img, Gh, Gw, heads):
-    """x (f32 [rows, D], in place) += proj(window attention(qkv(h))) for 8 x 8-token windows (csrc/hiera.hip).  h f16 [rows, D]
-    contiguous; packed = (wqkv_p, bqkv_p, wo_p, bo) from lmx.sam.pack_hiera_attn."""
+def hiera_attn8(x, packed, n_img, Gh, Gw, heads, h=None, ln=None):
+    """x (f32 [rows, D], in place) += proj(window attention(qkv(layer_norm1(x)))) for 8 x 8-token windows (csrc/hiera.hip).
+    Either h = layer_norm1(x) as f16 [rows, D] (packed from pack_hiera_attn(..., ln_inside=False)) or ln = (gamma, beta, eps): the
+    kernel normalises x itself (packed with ln_inside=True).  packed = (wqkv_p, bqkv_p, wo_p, bo)."""
     wq, bq, wo, bo = packed
-    dev = _dev(h, x, wq, bq, wo, bo)
+    if (h is None) == (ln is None):
+        raise LmxError("hiera_attn8: give either h or ln=(gamma, beta, eps)")
+    gamma, beta, eps = ln if ln is not None else (None, None, 0.0)
+    dev = _dev(x, h, gamma, beta, wq, bq, wo, bo)
     rows, D, ldx = _rows(x, "hiera_attn8 x")
-    if x.dtype != torch.float32 or h.dtype != torch.float16 or tuple(h.shape) != (rows, D) or not h.is_contiguous() or rows != n_img * Gh * Gw:
-        raise LmxError("hiera_attn8: h must be contiguous float16 [n*Gh*Gw, D] and x float32 rows of the same count")
+    if x.dtype != torch.float32 or rows != n_img * Gh * Gw:
+        raise LmxError("hiera_attn8: x must be float32 [n*Gh*Gw, D]")
+    if h is not None and (h.dtype != torch.float16 or tuple(h.shape) != (rows, D) or not h.is_contiguous()):
+        raise LmxError("hiera_attn8: h must be contiguous float16 [rows, D]")
+    if ln is not None and (gamma.numel() != D or beta.numel() != D or gamma.dtype != torch.float32 or beta.dtype != torch.float32):
+        raise LmxError("hiera_attn8: gamma / beta must be float32 [D]")
     if tuple(wq.shape) != (3 * heads * 64, 128) or tuple(wo.shape) != (D, heads * 64) or wq.dtype != torch.float16 or wo.dtype != torch.float16 \
             or not (wq.is_contiguous() and wo.is_contiguous()) or bq.numel() != 3 * heads * 64 or bo.numel() != D:
         raise LmxError("hiera_attn8: packed operands have the wrong shapes (lmx.sam.pack_hiera_attn)")
-    check(_lib.load().lmx_k_hiera_attn8(_ptr(h), _ptr(x), ldx, _ptr(wq), _ptr(bq), _ptr(wo), _ptr(bo), n_img, Gh, Gw, D, heads,
-                                        float((D // heads) ** -0.5), _stream(dev)), "lmx_k_hiera_attn8")
+    check(_lib.load().lmx_k_hiera_attn8(_ptr(h), _ptr(x), ldx, _ptr(gamma), _ptr(beta), float(eps), _ptr(wq), _ptr(bq), _ptr(wo), _ptr(bo),
+                                        n_img, Gh, Gw, D, heads, float((D // heads) ** -0.5), _stream(dev)), "lmx_k_hiera_attn8")
     return x
 
 

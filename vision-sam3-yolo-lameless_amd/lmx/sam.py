@@ -104,21 +104,25 @@ def sam_norm_lut():
     return ((u[None, :] - m[:, None]) / s[:, None]).astype(np.float32)
 
 
-def pack_hiera_attn(wqkv, bqkv, wo, bo, heads):
+def pack_hiera_attn(wqkv, bqkv, wo, bo, heads, ln_inside=False):
     """Operands of lmx_k_hiera_attn8 (csrc/hiera.hip) from the block's torch-layout parameters: wqkv [3D, D], bqkv [3D], wo [D, D],
     bo [D] (numpy, f32).  Returns (wqkv_p f16 [3*heads*64, 128], bqkv_p f32 [3*heads*64], wo_p f16 [D, heads*64], bo f32 [D]):
-    q | k | v sections with each head padded from D/heads to 64 rows and the inputs to 128 columns; v's row 63 of every head is zero
-    with bias 1 (the softmax sum then rides the PV product); the 64 columns of a head in wo_p are in MFMA k-slot order."""
+    q | k | v sections with each head padded from D/heads to 64 rows; v's row 63 of every head is zero with bias 1 (the softmax sum
+    then rides the PV product); the 64 columns of a head in wo_p — and, with ln_inside (the kernel normalises the f32 rows itself
+    and holds them in accumulator layout), the 128 input columns of wqkv_p — are in MFMA k-slot order: position 32 s + 8 g + 4 h + i
+    holds feature 16 (2 s + h) + 4 g + i, the order in which an accumulator tile is an operand."""
     D = wo.shape[0]
     hd = D // heads
     if hd > 63 or D > 128:
         raise ValueError("pack_hiera_attn: head dim <= 63 and D <= 128")
     wq = np.zeros((3 * heads * 64, 128), np.float32)
     bq = np.zeros((3 * heads * 64,), np.float32)
+    pos = np.array([32 * s_ + 8 * g + 4 * hb + i for s_ in range(4) for hb in range(2) for g in range(4) for i in range(4)])  # of feature 16(2s+hb)+4g+i
+    pos = pos[:D] if ln_inside else np.arange(D)
     for sec in range(3):
         for hh in range(heads):
             r0 = sec * heads * 64 + hh * 64
-            wq[r0:r0 + hd, :D] = wqkv[sec * D + hh * hd: sec * D + (hh + 1) * hd]
+            wq[r0:r0 + hd, pos] = wqkv[sec * D + hh * hd: sec * D + (hh + 1) * hd]
             bq[r0:r0 + hd] = bqkv[sec * D + hh * hd: sec * D + (hh + 1) * hd]
             if sec == 2:
                 bq[r0 + 63] = 1.0
@@ -180,9 +184,12 @@ class HieraEncoder:
             if dim != dim_out:
                 blk["wp"], blk["bp"] = t16(sd[p + "proj.weight"]), t32(sd[p + "proj.bias"])
             if dim == dim_out == 112 and heads == 2 and win_ == 8 and not qs:  # stage 1 of Hiera-B+: one kernel per attention half
+                # (the first block normalises in the kernel; later ones read the rows their predecessor's fused MLP left: see trunk)
+                blk["attn8_ln"] = i == 0 or not (self.fused_mlp and dim in K.FUSED_MLP_WIDTHS)
                 blk["attn8"] = tuple(torch.from_numpy(a).to(dev) for a in pack_hiera_attn(
                     np.asarray(sd[p + "attn.qkv.weight"], np.float32), np.asarray(qkv_b, np.float32),
-                    np.asarray(sd[p + "attn.proj.weight"], np.float32), np.asarray(sd[p + "attn.proj.bias"], np.float32), heads))
+                    np.asarray(sd[p + "attn.proj.weight"], np.float32), np.asarray(sd[p + "attn.proj.bias"], np.float32), heads,
+                    ln_inside=blk["attn8_ln"]))
             self.blocks.append(blk)
         n = len(cfg.dims) - 1
         self.neck = [(t16(sd[f"neck.convs.{n - i}.weight"][:, :, 0, 0]), t32(sd[f"neck.convs.{n - i}.bias"])) for i in range(n + 1)]
@@ -224,34 +231,36 @@ class HieraEncoder:
         dev = x.device
         h_next = None
         for i, B in enumerate(self.blocks):
-            dim, D, heads, win, qs = B["dim"], B["dim_out"], B["heads"], B["win"], B["qs"]
-            hd = D // heads
+            dim, D, heads, qs = B["dim"], B["dim_out"], B["heads"], B["qs"]
             rows = n * H * W
-            # (a block whose predecessor ran the fused MLP gets its LayerNorm from that kernel: h_next)
-            h = h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps)
-            h_next = None
-            if dim != D:
-                if qs and K.pooled_gemm_ok(rows, D):  # the shortcut's projection and its 2 x 2 max-pool in one launch
-                    sc = K.gemm(h, B["wp"], bias=B["bp"], out_dtype=torch.float32, pool_hw=(H, W))
+            if self._attn8(i, H, W):  # [layer_norm1 ->] qkv -> window attention -> proj + residual in one launch (csrc/hiera.hip)
+                if B["attn8_ln"]:
+                    K.hiera_attn8(x, B["attn8"], n, H, W, heads, ln=(B["g1"], B["b1"], cfg.eps))
                 else:
-                    sc = K.gemm(h, B["wp"], bias=B["bp"], out_dtype=torch.float32)
-                    if qs:
-                        pooled = torch.empty((n, H // 2, W // 2, D), dtype=torch.float32, device=dev)
-                        K.maxpool2(sc.view(n, H, W, D), pooled)
-                        sc = pooled.view(-1, D)
-                res = sc
+                    K.hiera_attn8(x, B["attn8"], n, H, W, heads, h=h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps))
             else:
-                res = x
-            if "attn8" in B and res is x and K.hiera_attn8_ok(D, heads, win, H, W, qs):
-                K.hiera_attn8(h, x, B["attn8"], n, H, W, heads)  # qkv -> window attention -> proj + residual in one launch (csrc/hiera.hip)
-            else:
+                # (a block whose predecessor ran the fused MLP gets its LayerNorm from that kernel: h_next)
+                h = h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps)
+                if dim != D:
+                    if qs and K.pooled_gemm_ok(rows, D):  # the shortcut's projection and its 2 x 2 max-pool in one launch
+                        sc = K.gemm(h, B["wp"], bias=B["bp"], out_dtype=torch.float32, pool_hw=(H, W))
+                    else:
+                        sc = K.gemm(h, B["wp"], bias=B["bp"], out_dtype=torch.float32)
+                        if qs:
+                            pooled = torch.empty((n, H // 2, W // 2, D), dtype=torch.float32, device=dev)
+                            K.maxpool2(sc.view(n, H, W, D), pooled)
+                            sc = pooled.view(-1, D)
+                    res = sc
+                else:
+                    res = x
                 x, H, W = self._attention_half(B, h, x, res, n, H, W)
+            h_next = None
             x16 = None
             if D in K.FUSED_MLP_WIDTHS and self.fused_mlp:
                 if i in stage_ends:  # the FPN's lateral convolution reads this stage output as f16: written here, not cast later
                     x16 = torch.empty((n * H * W, D), dtype=torch.float16, device=dev)
                 nxt = None
-                if i + 1 < len(self.blocks):  # the next block's layer_norm1, on the rows while the kernel still holds them
+                if i + 1 < len(self.blocks) and not (self._attn8(i + 1, H, W) and self.blocks[i + 1]["attn8_ln"]):  # the next block's layer_norm1, on the rows while the kernel still holds them
                     h_next = torch.empty((n * H * W, D), dtype=torch.float16, device=dev)
                     nxt = (self.blocks[i + 1]["g1"], self.blocks[i + 1]["b1"], h_next)
                 K.ln_mlp(x, B["g2"], B["b2"], B["w1"], B["bb1"], B["w2"], B["bb2"], cfg.eps, x16=x16, next_ln=nxt)  # one pass over x (csrc/mlp.hip)
@@ -265,6 +274,11 @@ class HieraEncoder:
                 if i != len(self.blocks) - 1 and self.blocks[i + 1]["dim"] == self.blocks[i + 1]["dim_out"]:
                     x = x.clone()  # the stage output is kept; a same-width next block would update it in place
         return stages, stages16  # stages16: f16 copies of the stage outputs where the stage's last kernel wrote one (else None)
+
+    def _attn8(self, i, H, W):
+        """Block i runs its attention half (layer_norm1 included) in lmx_k_hiera_attn8."""
+        B = self.blocks[i]
+        return "attn8" in B and B["dim"] == B["dim_out"] and K.hiera_attn8_ok(B["dim_out"], B["heads"], B["win"], H, W, B["qs"])
 
     def _attention_half(self, B, h, x, res, n, H, W):
         """qkv GEMM -> [Q-pool] -> attention -> proj GEMM + residual as separate launches; returns (x, H, W) after the block's pooling."""
