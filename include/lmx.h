@@ -118,6 +118,16 @@ int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const float* gamma, 
                       const float* bqkv_p, const void* wo_p, const float* bo, int n_img, int Gh, int Gw, int D, int heads, float scale,
                       lmx_stream_t stream);
 
+/* The same for Hiera-B+ stage 2 (D = 224, 4 heads of 56, 4 x 4-token windows; blocks whose input and output widths are equal): the
+ * three launches qkv GEMM -> window attention -> projection GEMM (+ residual) as one kernel whose weights stream through an LDS ring
+ * (csrc/hiera.hip).  h f16 [rows, D] contiguous = layer_norm1(x) (the previous block's lmx_k_ln_mlp leaves it as h_next); x f32
+ * [rows, ldx] updated in place; rows = n_img * Gh * Gw, Gh and Gw multiples of 4.  w_img f16 [16][16384]: per head h the LDS
+ * images of its q, k, v (64 rows x 512 B, 16-byte chunk c of row r at c ^ (r & 15), rows >= 56 zero, v's row 63 zero with bias 1)
+ * and projection (256 rows x 128 B, chunk c of row r at c ^ ((r >> 1) & 7), the head's 64 input columns in MFMA k-slot order)
+ * matrices at index 4 h + {0, 1, 2, 3}; bias f32 [4][q | k | v][64] then the projection's [224] (lmx/sam.py pack_hiera_attn4). */
+int lmx_k_hiera_attn4(const void* h, float* x, int64_t ldx, const void* w_img, const float* bias, int n_img, int Gh, int Gw, int D,
+                      int heads, float scale, lmx_stream_t stream);
+
 /* ---- K11+K12 for narrow widths: x += fc2(gelu(fc1(LayerNorm(x)))) without the 4D-wide hidden tensor ever reaching HBM ----
  * Replaces `hidden_states + self.mlp(self.layer_norm2(hidden_states))` of the Hiera blocks whose width is 112 or 224
  * (TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward; stages 1-2 of Hiera-B+), where the unfused

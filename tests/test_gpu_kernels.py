@@ -526,3 +526,40 @@ def test_hiera_attn8_fused_block(cuda, n, Gh, Gw, ln_inside):
     print(f"hiera_attn8 n{n} {Gh}x{Gw}: max |fused - unfused| {d:.3e}, max |fused - fp32| {(xd.cpu() - ref).abs().max().item():.3e}, "
           f"max |unfused - fp32| {(xu.cpu() - ref).abs().max().item():.3e}")
     assert d < 4e-3
+
+
+@pytest.mark.parametrize("n,Gh,Gw", [(1, 4, 4), (1, 8, 12), (2, 32, 32), (3, 20, 28)])
+def test_hiera_attn4_fused_block(cuda, n, Gh, Gw):
+    """lmx_k_hiera_attn4 (csrc/hiera.hip): x += proj(window attention(qkv(h))) for 4 x 4-token windows at D = 224 (4 heads), weights
+    streamed through LDS; against the fp32 definition and the three launches it replaces.  The grids cover a partial last group of
+    16 windows, a single window, and several groups per workgroup."""
+    from lmx import kernels as Kk
+    from lmx import sam
+
+    D, heads, hd = 224, 4, 56
+    rows = n * Gh * Gw
+    h = _rand((rows, D), 81, 1.0).half()
+    x = _rand((rows, D), 82, 1.0)
+    wqkv = (_rand((3 * D, D), 83, 1.0) * D ** -0.5).half().float()
+    bqkv = _rand((3 * D,), 84, 0.2)
+    wo = (_rand((D, D), 85, 1.0) * D ** -0.5).half().float()
+    bo = _rand((D,), 86, 0.2)
+    qkv = h.float() @ wqkv.t() + bqkv
+    t = qkv.view(n, Gh // 4, 4, Gw // 4, 4, 3, heads, hd).permute(5, 0, 1, 3, 6, 2, 4, 7).reshape(3, -1, heads, 16, hd)
+    att = torch.softmax(t[0] @ t[1].transpose(-1, -2) * hd ** -0.5, -1) @ t[2]
+    att = att.view(n, Gh // 4, Gw // 4, heads, 4, 4, hd).permute(0, 1, 4, 2, 5, 3, 6).reshape(rows, D)
+    ref = x + att @ wo.t() + bo
+    packed = tuple(torch.from_numpy(a).to(cuda) for a in sam.pack_hiera_attn4(wqkv.numpy(), bqkv.numpy(), wo.numpy(), bo.numpy(), heads))
+    xd = x.to(cuda)
+    Kk.hiera_attn4(h.to(cuda), xd, packed, n, Gh, Gw, heads)
+    _close(xd, ref, 4e-3, 4e-3, f"hiera_attn4 n{n} {Gh}x{Gw} vs fp32")
+    q3 = Kk.gemm(h.to(cuda), wqkv.half().to(cuda), bias=bqkv.to(cuda))
+    a = torch.empty((rows, D), dtype=torch.float16, device=cuda)
+    Kk.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], a, n * (Gh // 4) * (Gw // 4), heads, 16, 16, hd, hd ** -0.5,
+                 window=dict(Gh=Gh, Gw=Gw, ws=4, q_stride=1), pad_k=q3[0, D:2 * D].contiguous(), pad_v=q3[0, 2 * D:].contiguous())
+    xu = x.to(cuda)
+    Kk.gemm(a, wo.half().to(cuda), bias=bo.to(cuda), res=xu, out=xu)
+    d = (xd - xu).abs().max().item()
+    print(f"hiera_attn4 n{n} {Gh}x{Gw}: max |fused - unfused| {d:.3e}, max |fused - fp32| {(xd.cpu() - ref).abs().max().item():.3e}, "
+          f"max |unfused - fp32| {(xu.cpu() - ref).abs().max().item():.3e}")
+    assert d < 4e-3

@@ -45,3 +45,31 @@ for n, G in ((30, 256), (10, 256)):
     print(f"{n} frames: LayerNorm launch {t_l * 1e3:.0f} us; fused on precomputed LayerNorm rows {t_h * 1e3:.0f} us", flush=True)
     print(f"{n} frames: unfused (LayerNorm + qkv GEMM + window attention + proj GEMM) {t_u * 1e3:.0f} us, fused incl. LayerNorm {t_f * 1e3:.0f} us "
           f"({rows * 896 / t_f / 1e9:.2f} TB/s algorithmic, {rows / 64 * 624 * 16384 / t_f / 1e9:.0f} TFLOP/s issued)", flush=True)
+
+# stage 2: D = 224, 4 heads, 4 x 4 windows, 30 frames x 128 x 128 tokens (lmx_k_hiera_attn4: weights streamed)
+D, heads, hd = 224, 4, 56
+for n, G in ((30, 128), (10, 128)):
+    rows = n * G * G
+    g = torch.Generator().manual_seed(6)
+    h = torch.randn((rows, D), generator=g).half().to(dev)
+    x = torch.randn((rows, D), generator=g).to(dev)
+    wqkv = (torch.randn((3 * D, D), generator=g) * D ** -0.5).half().float()
+    bqkv = torch.randn((3 * D,), generator=g) * 0.2
+    wo = (torch.randn((D, D), generator=g) * D ** -0.5).half().float()
+    bo = torch.randn((D,), generator=g) * 0.2
+    packed4 = tuple(torch.from_numpy(a).to(dev) for a in sam.pack_hiera_attn4(wqkv.numpy(), bqkv.numpy(), wo.numpy(), bo.numpy(), heads))
+    w16, wo16, bq, bod = wqkv.half().to(dev), wo.half().to(dev), bqkv.to(dev), bo.to(dev)
+    a = torch.empty((rows, D), dtype=torch.float16, device=dev)
+    pk, pv = torch.zeros(D, dtype=torch.float16, device=dev), torch.zeros(D, dtype=torch.float16, device=dev)
+
+    def unfused4():
+        q3 = K.gemm(h, w16, bias=bq)
+        K.attention(q3[:, :D], q3[:, D:2 * D], q3[:, 2 * D:], a, n * (G // 4) ** 2, heads, 16, 16, hd, hd ** -0.5,
+                    window=dict(Gh=G, Gw=G, ws=4, q_stride=1), pad_k=pk, pad_v=pv)
+        K.gemm(a, wo16, bias=bod, res=x, out=x)
+
+    t_u = timeit(unfused4, iters=5)
+    x.normal_()
+    t_f = timeit(lambda: K.hiera_attn4(h, x, packed4, n, G, G, heads), iters=5)
+    print(f"stage 2, {n} frames: unfused (qkv GEMM + window attention + proj GEMM) {t_u * 1e3:.0f} us, fused {t_f * 1e3:.0f} us "
+          f"({rows * 2240 / t_f / 1e9:.2f} TB/s algorithmic)", flush=True)

@@ -341,3 +341,216 @@ extern "C" int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const flo
     hipLaunchKernelGGL(hiera_attn8_kernel<true>, dim3(grid), dim3(256), SMEM, st, hp, x, ldx, gamma, beta, eps, wq, bqkv_p, wop, bo, Gh, Gw, (int)nwin, sl2);
   return lmx_launch_check("hiera_attn8_kernel");
 }
+
+// ================================================================================================================================
+// Stage 2 of Hiera-B+ (D = 224, 4 heads of 56, 4 x 4-token windows): the same idea — a window's rows stay in registers from the qkv
+// projection through attention and the output projection — but the weights (4 heads x (q | k | v | proj) = 16 matrices of 32 KB)
+// do not fit in LDS and STREAM through a four-slot ring by LDS-DMA, one matrix per step, exactly as csrc/mlp.hip streams its chunks:
+// counted s_waitcnt vmcnt for the wave's own pieces, ONE raw s_barrier per matrix, the slot freed by that barrier refilled with the
+// matrix three steps ahead.  The host stores every matrix as its LDS image (lmx/sam.py pack_hiera_attn4), so a DMA piece is a
+// linear 1 KB copy.  A workgroup = 8 waves x 2 windows = 256 tokens per pass over the weights (512 KB from L2); a window is one
+// 16-token MFMA block, so S and PV are block-diagonal: S^T = K . Q^T is one 16 x 16 tile per (window, head), PV runs on
+// v_mfma_f32_16x16x16_f16 whose four k-slots per lane ARE the accumulator layout (keys 4g .. 4g+3) — no padding of the 16 keys.
+// layer_norm1's rows come from the previous block's fused MLP (h_next).  Rounding points as in the unfused chain.
+namespace {
+
+constexpr int D4 = 224, HEADS4 = 4, KS4 = 7, TB4 = 2, NW4 = 8;
+constexpr int MAT = 32768;                 // bytes of one matrix image (q | k | v: 64 rows x 512 B; proj: 256 rows x 128 B)
+constexpr int NST4 = 4, LA4 = NST4 - 1, PT4 = MAT / (NW4 * 1024);  // ring slots, matrices in flight, DMA pieces per wave and matrix
+constexpr int NB4 = HEADS4 * 3 * 64 + D4;  // biases: [head][q | k | v][64] then the projection's
+constexpr int SMEM4 = NST4 * MAT + NB4 * 4;
+
+typedef __fp16 half4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(NW4 * 64, 2) void hiera_attn4_kernel(const half_t* __restrict__ h, float* __restrict__ x, const int64_t ldx,
+                                                                   const half_t* __restrict__ img, const float* __restrict__ bias_g,
+                                                                   const int Gh, const int Gw, const int nwin, const int ngroup,
+                                                                   const float sl2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias = reinterpret_cast<float*>(smem + NST4 * MAT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int i = tid; i < NB4; i += NW4 * 64) bias[i] = bias_g[i];
+
+  // ---- the weight stream: matrix c (counted over this workgroup's groups) is image c % 16 and lands in slot c % NST4
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(img), 0, 16 * MAT, 0x00020000);
+  const int my_groups = (ngroup - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int ctotal = my_groups * 16;
+  const unsigned voff = (unsigned)(wave * (PT4 * 1024) + lane * 16);
+  auto issue = [&](const int c) {
+    char* dst = smem + (c % NST4) * MAT + wave * (PT4 * 1024);
+#pragma unroll
+    for (int t = 0; t < PT4; ++t) lds_dma16(w_rs, dst + t * 1024, voff + t * 1024, (c & 15) * MAT);
+  };
+#pragma unroll
+  for (int c = 0; c < LA4; ++c)
+    if (c < ctotal) issue(c);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // bias: a raw s_barrier does not wait for this wave's LDS writes
+
+  const int nWx = Gw >> 2, nWy = Gh >> 2;
+  int c = 0;
+  for (int grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+    // this wave's two windows; a window past the last one computes on window 0 and stores nothing
+    int64_t row[TB4];
+    bool live[TB4];
+#pragma unroll
+    for (int tb = 0; tb < TB4; ++tb) {
+      const int w = grp * (NW4 * TB4) + wave * TB4 + tb;
+      live[tb] = w < nwin;
+      const int wc = live[tb] ? w : 0;
+      const int im = wc / (nWy * nWx), wi = wc - im * (nWy * nWx);
+      const int wy = wi / nWx, wx = wi - wy * nWx;
+      row[tb] = ((int64_t)im * Gh + wy * 4 + (fr >> 2)) * Gw + wx * 4 + (fr & 3);
+    }
+    half8_t xn[TB4][KS4];
+#pragma unroll
+    for (int tb = 0; tb < TB4; ++tb)
+#pragma unroll
+      for (int ks = 0; ks < KS4; ++ks) xn[tb][ks] = *reinterpret_cast<const half8_t*>(h + row[tb] * D4 + ks * 32 + fg * 8);
+    f32x4 accp[14][TB4];
+#pragma unroll
+    for (int ob = 0; ob < 14; ++ob) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + HEADS4 * 192 + ob * 16 + fg * 4);
+#pragma unroll
+      for (int tb = 0; tb < TB4; ++tb) accp[ob][tb] = *reinterpret_cast<const f32x4*>(x + row[tb] * ldx + ob * 16 + fg * 4) + bv;
+    }
+
+    // one step of the stream: matrix c has landed for every wave, every wave is done with matrix c - 1, whose slot is refilled
+    auto step = [&]() -> const char* {
+      const int left = ctotal - 1 - c;
+      wait_tiles<PT4>(left < LA4 - 1 ? left : LA4 - 1);
+      __builtin_amdgcn_s_barrier();
+      if (c + LA4 < ctotal) issue(c + LA4);
+      const char* m = smem + (c % NST4) * MAT;
+      ++c;
+      return m;
+    };
+
+#pragma unroll 1
+    for (int hh = 0; hh < HEADS4; ++hh) {
+      half8_t qf[TB4][2], kf[TB4][2];
+#pragma unroll
+      for (int sec = 0; sec < 2; ++sec) {  // q^T, k^T: [64 d][16 tokens] per window
+        const char* m = step();
+        f32x4 acc[4][TB4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + hh * 192 + sec * 64 + rb * 16 + fg * 4);
+#pragma unroll
+          for (int tb = 0; tb < TB4; ++tb) acc[rb][tb] = bv;
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int ks = 0; ks < KS4; ++ks) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(m + (rb * 16 + fr) * 512 + ((((ks << 2) + fg) ^ fr) << 4));
+#pragma unroll
+            for (int tb = 0; tb < TB4; ++tb) acc[rb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[rb][tb], 0, 0, 0);
+          }
+#pragma unroll
+        for (int tb = 0; tb < TB4; ++tb)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const half8_t f = pack8(acc[2 * s][tb], acc[2 * s + 1][tb]);
+            if (sec == 0)
+              qf[tb][s] = f;
+            else
+              kf[tb][s] = f;
+          }
+      }
+      half8_t of[TB4][2];
+      {  // v: [16 tokens][64 d] per window (tokens are the MFMA rows), then the window's attention for this head
+        const char* m = step();
+        f32x4 acc[TB4][4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const float b = bias[hh * 192 + 128 + db * 16 + fr];
+#pragma unroll
+          for (int tb = 0; tb < TB4; ++tb) acc[tb][db] = f32x4{b, b, b, b};
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int ks = 0; ks < KS4; ++ks) {
+            const half8_t bw = *reinterpret_cast<const half8_t*>(m + (db * 16 + fr) * 512 + ((((ks << 2) + fg) ^ fr) << 4));
+#pragma unroll
+            for (int tb = 0; tb < TB4; ++tb) acc[tb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb][db], 0, 0, 0);
+          }
+#pragma unroll
+        for (int tb = 0; tb < TB4; ++tb) {
+          // S^T[key][query] of the window: lane (query fr, fg) holds keys 4 fg .. 4 fg + 3
+          f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 2; ++s) sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[tb][s], qf[tb][s], sc, 0, 0, 0);
+          const float nmb = -(hrow_max4(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])) * sl2);
+          half4v pf;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pf[r] = (half_t)__builtin_amdgcn_exp2f(fmaf(sc[r], sl2, nmb));
+          // O^T[d][query] = V^T . P^T over the 16 keys: v_mfma_f32_16x16x16_f16, k-slot 4 g + i = key 4 g + i (both accumulator layouts)
+          f32x4 oacc[4];
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            const half4v vf = {(half_t)acc[tb][db][0], (half_t)acc[tb][db][1], (half_t)acc[tb][db][2], (half_t)acc[tb][db][3]};
+            oacc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          }
+          const float l = __shfl(oacc[3][3], 48 + fr, 64);  // row 63: the softmax sum (v's column 63 is the constant 1)
+          const float inv = 1.0f / l;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) of[tb][s] = pack8(oacc[2 * s] * inv, oacc[2 * s + 1] * inv);
+        }
+      }
+      {  // x^T[o][token] += Wo[:, head hh] . O^T  (image rows of 128 B: 8 chunks, chunk c of row r at c ^ ((r >> 1) & 7))
+        const char* m = step();
+#pragma unroll
+        for (int ob = 0; ob < 14; ++ob)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(m + (ob * 16 + fr) * 128 + ((((s << 2) + fg) ^ ((fr >> 1) & 7)) << 4));
+#pragma unroll
+            for (int tb = 0; tb < TB4; ++tb) accp[ob][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, of[tb][s], accp[ob][tb], 0, 0, 0);
+          }
+      }
+    }
+#pragma unroll
+    for (int tb = 0; tb < TB4; ++tb)
+      if (live[tb]) {
+#pragma unroll
+        for (int ob = 0; ob < 14; ++ob) *reinterpret_cast<f32x4*>(x + row[tb] * ldx + ob * 16 + fg * 4) = accp[ob][tb];
+      }
+  }
+}
+
+}  // namespace
+
+// h f16 [rows, 224] contiguous = layer_norm1(x); x f32 [rows, ldx] updated in place; rows = n_img * Gh * Gw, Gh and Gw multiples of 4.
+// w_img f16 [16][16384]: the LDS images of head h's q, k, v and projection matrices at index 4 h + {0, 1, 2, 3}; bias f32
+// [4 * 192 + 224] (lmx/sam.py pack_hiera_attn4).
+extern "C" int lmx_k_hiera_attn4(const void* h, float* x, int64_t ldx, const void* w_img, const float* bias, int n_img, int Gh, int Gw,
+                                 int D_, int heads, float scale, lmx_stream_t stream) {
+  LMX_REQUIRE(h && x && w_img && bias, "lmx_k_hiera_attn4: null pointer");
+  LMX_REQUIRE(D_ == D4 && heads == HEADS4, "lmx_k_hiera_attn4: built for D = 224 with 4 heads, got D = %d heads = %d", D_, heads);
+  LMX_REQUIRE(n_img > 0 && Gh > 0 && Gw > 0 && Gh % 4 == 0 && Gw % 4 == 0, "lmx_k_hiera_attn4: token grid %d x %d is not whole 4 x 4 windows", Gh, Gw);
+  LMX_REQUIRE(ldx >= D4 && ldx % 4 == 0 && aligned16(h) && aligned16(x) && aligned16(w_img), "lmx_k_hiera_attn4: ldx / alignment");
+  const int64_t nwin = (int64_t)n_img * (Gh / 4) * (Gw / 4);
+  LMX_REQUIRE(nwin < (1ll << 31), "lmx_k_hiera_attn4: too many windows");
+  const int64_t ngroup = (nwin + NW4 * TB4 - 1) / (NW4 * TB4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_attn4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM4));
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    LMX_HIP(hipGetDevice(&dev));
+    LMX_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const unsigned grid = (unsigned)(ngroup < n_cu ? ngroup : n_cu);
+  hipLaunchKernelGGL(hiera_attn4_kernel, dim3(grid), dim3(NW4 * 64), SMEM4, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const half_t*>(h), x, ldx, reinterpret_cast<const half_t*>(w_img), bias, Gh, Gw, (int)nwin, (int)ngroup,
+                     scale * 1.44269504088896340736f);
+  return lmx_launch_check("hiera_attn4_kernel");
+}

@@ -302,6 +302,27 @@ def hiera_attn8(x, packed, n_img, Gh, Gw, heads, h=None, ln=None):
     return x
 
 
+def hiera_attn4_ok(D, heads, win, Gh, Gw, q_stride):
+    """Shapes lmx_k_hiera_attn4 is built for: Hiera-B+ stage 2 (D 224, 4 heads of 56), whole 4 x 4 windows, no query pooling."""
+    return D == 224 and heads == 4 and win == 4 and not q_stride and Gh % 4 == 0 and Gw % 4 == 0 and os.environ.get("LMX_HIERA_ATTN4", "1") != "0"
+
+
+def hiera_attn4(h, x, packed, n_img, Gh, Gw, heads):
+    """x (f32 [rows, D], in place) += proj(window attention(qkv(h))) for 4 x 4-token windows, weights streamed (csrc/hiera.hip).
+    h f16 [rows, D] contiguous = layer_norm1(x); packed = (w_img, bias) from lmx.sam.pack_hiera_attn4."""
+    img, bias = packed
+    dev = _dev(h, x, img, bias)
+    rows, D, ldx = _rows(x, "hiera_attn4 x")
+    if x.dtype != torch.float32 or h.dtype != torch.float16 or tuple(h.shape) != (rows, D) or not h.is_contiguous() or rows != n_img * Gh * Gw:
+        raise LmxError("hiera_attn4: h must be contiguous float16 [n*Gh*Gw, D] and x float32 rows of the same count")
+    if tuple(img.shape) != (4 * heads, 16384) or img.dtype != torch.float16 or not img.is_contiguous() or bias.numel() != heads * 192 + D \
+            or bias.dtype != torch.float32:
+        raise LmxError("hiera_attn4: packed operands have the wrong shapes (lmx.sam.pack_hiera_attn4)")
+    check(_lib.load().lmx_k_hiera_attn4(_ptr(h), _ptr(x), ldx, _ptr(img), _ptr(bias), n_img, Gh, Gw, D, heads, float((D // heads) ** -0.5),
+                                        _stream(dev)), "lmx_k_hiera_attn4")
+    return x
+
+
 def _attn_desc(q, k, v, out, B, H, Tq, Tk, hd, scale, window, pad_k, pad_v):
     d = AttnDesc()
     d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()

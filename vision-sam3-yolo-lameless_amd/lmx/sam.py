@@ -138,6 +138,45 @@ def pack_hiera_attn(wqkv, bqkv, wo, bo, heads, ln_inside=False):
     return wq.astype(np.float16), bq, wop.astype(np.float16), np.ascontiguousarray(bo, dtype=np.float32)
 
 
+def pack_hiera_attn4(wqkv, bqkv, wo, bo, heads):
+    """Operands of lmx_k_hiera_attn4 (csrc/hiera.hip): the LDS images of the 4 * heads matrices the kernel streams, and its biases.
+    wqkv [3D, D], bqkv [3D], wo [D, D], bo [D] (numpy, f32; D = 224, heads = 4).  Image 4 h + s, s in q | k | v: 64 rows (the
+    head's 56, then zeros) of 512 bytes, the 16-byte chunk c of row r stored at chunk c ^ (r & 15); image 4 h + 3: the projection's
+    columns of head h as 256 rows (224 outputs, then zeros) of 128 bytes, chunk c of row r at c ^ ((r >> 1) & 7), the 64 columns in
+    MFMA k-slot order (position 32 s + 8 g + 4 hb + i holds the head's input 16 (2 s + hb) + 4 g + i, zeros past 56).
+    bias: [head][q | k | v][64] (v's entry 63 is 1: the softmax sum rides the PV product) then bo."""
+    D = wo.shape[0]
+    hd = D // heads
+    img = np.zeros((4 * heads, 16384), np.float16)
+    bias = np.zeros((heads * 192 + D,), np.float32)
+    for hh in range(heads):
+        for sec in range(3):
+            m = np.zeros((64, 256), np.float16)
+            m[:hd, :D] = wqkv[sec * D + hh * hd: sec * D + (hh + 1) * hd].astype(np.float16)
+            ch = m.reshape(64, 32, 8)
+            out = np.zeros_like(ch)
+            for r in range(64):
+                out[r, np.arange(32) ^ (r & 15)] = ch[r]
+            img[4 * hh + sec] = out.reshape(-1)
+            bias[hh * 192 + sec * 64: hh * 192 + sec * 64 + hd] = bqkv[sec * D + hh * hd: sec * D + (hh + 1) * hd]
+        bias[hh * 192 + 128 + 63] = 1.0
+        m = np.zeros((256, 64), np.float16)
+        for s_ in range(2):
+            for g in range(4):
+                for hb in range(2):
+                    for i in range(4):
+                        d = 16 * (2 * s_ + hb) + 4 * g + i
+                        if d < hd:
+                            m[:D, 32 * s_ + 8 * g + 4 * hb + i] = wo[:, hh * hd + d].astype(np.float16)
+        ch = m.reshape(256, 8, 8)
+        out = np.zeros_like(ch)
+        for r in range(256):
+            out[r, np.arange(8) ^ ((r >> 1) & 7)] = ch[r]
+        img[4 * hh + 3] = out.reshape(-1)
+    bias[heads * 192:] = bo
+    return img, bias
+
+
 class HieraEncoder:
     """Device-resident Hiera trunk + FPN.  ``encode(frames)`` -> dict(fpn=[3 NHWC f16 levels, high->low res],
     stages=[4 f32 stage outputs]).  Token grids are [n, H, W, C] row-major throughout (no partition copies)."""
@@ -190,6 +229,10 @@ class HieraEncoder:
                     np.asarray(sd[p + "attn.qkv.weight"], np.float32), np.asarray(qkv_b, np.float32),
                     np.asarray(sd[p + "attn.proj.weight"], np.float32), np.asarray(sd[p + "attn.proj.bias"], np.float32), heads,
                     ln_inside=blk["attn8_ln"]))
+            if dim == dim_out == 224 and heads == 4 and win_ == 4 and not qs:  # stage 2 (after its first block): the same, weights streamed
+                blk["attn4"] = tuple(torch.from_numpy(a).to(dev) for a in pack_hiera_attn4(
+                    np.asarray(sd[p + "attn.qkv.weight"], np.float32), np.asarray(qkv_b, np.float32),
+                    np.asarray(sd[p + "attn.proj.weight"], np.float32), np.asarray(sd[p + "attn.proj.bias"], np.float32), heads))
             self.blocks.append(blk)
         n = len(cfg.dims) - 1
         self.neck = [(t16(sd[f"neck.convs.{n - i}.weight"][:, :, 0, 0]), t32(sd[f"neck.convs.{n - i}.bias"])) for i in range(n + 1)]
@@ -238,6 +281,8 @@ class HieraEncoder:
                     K.hiera_attn8(x, B["attn8"], n, H, W, heads, ln=(B["g1"], B["b1"], cfg.eps))
                 else:
                     K.hiera_attn8(x, B["attn8"], n, H, W, heads, h=h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps))
+            elif "attn4" in B and K.hiera_attn4_ok(D, heads, B["win"], H, W, qs):  # the same for 4 x 4 windows at D = 224
+                K.hiera_attn4(h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps), x, B["attn4"], n, H, W, heads)
             else:
                 # (a block whose predecessor ran the fused MLP gets its LayerNorm from that kernel: h_next)
                 h = h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps)
