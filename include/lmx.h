@@ -128,6 +128,16 @@ int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const float* gamma, 
 int lmx_k_hiera_attn4(const void* h, float* x, int64_t ldx, const void* w_img, const float* bias, int n_img, int Gh, int Gw, int D,
                       int heads, float scale, lmx_stream_t stream);
 
+/* The block that opens Hiera-B+ stage 2 (112 -> 224 channels, 4 heads of 56; keys / values the 64 tokens of an 8 x 8 window, queries
+ * and shortcut their 2 x 2 max-pools; TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward with dim != dim_out and q_stride):
+ * shortcut GEMM + pool, q GEMM + pool, k | v GEMM, window attention with pooled queries, projection GEMM + residual as one kernel
+ * (csrc/hiera.hip; weights streamed).  h f16 [n_img*Gh*Gw, 112] contiguous = layer_norm1(x); out f32 [n_img*(Gh/2)*(Gw/2), 224]
+ * contiguous (written, not accumulated); Gh, Gw multiples of 8.  w_img f16 [14][16384]: LDS images — shortcut rows 0..127,
+ * shortcut rows 128..223, then per head [q | k] (2 x 64 rows of 256 B), [v | unused], projection columns of the head (256 rows of
+ * 128 B, k-slot order) —, bias f32 [224 shortcut | 4 x (q | k | v) x 64 | 224 projection] (lmx/sam.py pack_hiera_attn_pool). */
+int lmx_k_hiera_attn_pool(const void* h, float* out, const void* w_img, const float* bias, int n_img, int Gh, int Gw, int Din, int Dout,
+                          int heads, float scale, lmx_stream_t stream);
+
 /* ---- K11+K12 for narrow widths: x += fc2(gelu(fc1(LayerNorm(x)))) without the 4D-wide hidden tensor ever reaching HBM ----
  * Replaces `hidden_states + self.mlp(self.layer_norm2(hidden_states))` of the Hiera blocks whose width is 112 or 224
  * (TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward; stages 1-2 of Hiera-B+), where the unfused

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
 //    run under this tile's exponentials inside the same wave (a second accumulator set, 32 registers; sched_group_barrier
 //    interleaves one MFMA per four VALU instructions);
 //  * the one wave-uniform branch of a tile (did a running maximum grow? then rescale) sits before that block;
-//  * the row maximum is v_max3_f32 (fmaxf on MFMA results costs hipcc a canonicalising v_max per operand) and its cross-lane step
+//  * the row maximum is v_med3_f32 against +inf (fmaxf on MFMA results costs hipcc a canonicalising v_max per operand) and its cross-lane step
 //    v_permlane16_swap / v_permlane32_swap instead of two ds_bpermute round trips in the middle of the dependency chain.
 // Same MFMA order per accumulator, same exp2 arguments, same f16 roundings as attn_kernel<2, ONES, false, true, 64>: identical
 // bits (tools/attn_gp_probe.py), 1601 -> 1518 us at B = 30, H = 8 (profiles/r03_attn_gp.txt).  What the time is made of
@@ -472,10 +472,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const lmx_attn_desc p, con
 // DMA issue -15 %, without either MFMA group and its fragment reads -32 % each: the phases add up — per wave and tile ~1200 issue
 // cycles (32 MFMAs hold the vector issue for 8 of their 16 cycles, 34 v_exp_f32 at 8, ~150 other VALU at 4, 4 DMA pieces at
 // 60 - 100) against 512 matrix cycles.  At head dim 64 a score costs the same softmax as at 128 and feeds half the MFMA work.
+// (v_med3_f32 against +inf rather than inline-asm v_max3_f32: the operands are MFMA results, and hipcc inserts the wait states an
+// MFMA write -> VALU read needs only in front of instructions it knows; csrc/hiera.hip has the case that showed it)
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
+  return __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(a, b, INFINITY), c, INFINITY);
 }
 // maximum over the four 16-lane rows of a wave, delivered to every row (lane maps: tools/permlane_swap_probe.hip).  Two traps:
 // __builtin_bit_cast(float, a[1]) on an element of the returned 2-vector reads element 0 (hipcc 7.2 takes the vector's address):

@@ -43,10 +43,13 @@ constexpr int SMEM = B_OFF + (NQKV + 3 * D) * 4;  // + biases, LayerNorm gamma a
 __device__ __forceinline__ half8_t pack8(const f32x4 a, const f32x4 b) {
   return half8_t{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
 }
+// max(a, b, c) of finite values (or -inf) as two v_med3_f32 against +inf.  NOT inline asm (v_max3_f32): these run on MFMA results, and the
+// wait states gfx950 needs between an MFMA's write and a VALU read of the register are inserted by hipcc only in front of
+// instructions it knows — an asm v_max3 behind the S MFMAs read accumulators that were not written yet whenever a second wave kept
+// the matrix pipe busy (the maximum came out different from run to run: a valid softmax shift, so only the bit-reproducibility test
+// saw it, tools/hiera_pool_determinism.py); and not fmaxf, which costs a canonicalising v_max per operand on MFMA results.
 __device__ __forceinline__ float hmax3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
+  return __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(a, b, INFINITY), c, INFINITY);
 }
 // maximum over the four 16-lane rows of a wave, in every row (scalar temporaries: a bit_cast of a vector element reads element 0)
 __device__ __forceinline__ float hrow_max4(float ma, float mc) {
@@ -354,7 +357,10 @@ extern "C" int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const flo
 // layer_norm1's rows come from the previous block's fused MLP (h_next).  Rounding points as in the unfused chain.
 namespace {
 
-constexpr int D4 = 224, HEADS4 = 4, KS4 = 7, TB4 = 2, NW4 = 8;
+#ifndef LMX_H4_TB
+#define LMX_H4_TB 2
+#endif
+constexpr int D4 = 224, HEADS4 = 4, KS4 = 7, TB4 = LMX_H4_TB, NW4 = 16 / TB4;
 constexpr int MAT = 32768;                 // bytes of one matrix image (q | k | v: 64 rows x 512 B; proj: 256 rows x 128 B)
 constexpr int NST4 = 4, LA4 = NST4 - 1, PT4 = MAT / (NW4 * 1024);  // ring slots, matrices in flight, DMA pieces per wave and matrix
 constexpr int NB4 = HEADS4 * 3 * 64 + D4;  // biases: [head][q | k | v][64] then the projection's
@@ -362,7 +368,7 @@ constexpr int SMEM4 = NST4 * MAT + NB4 * 4;
 
 typedef __fp16 half4v __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(NW4 * 64, 2) void hiera_attn4_kernel(const half_t* __restrict__ h, float* __restrict__ x, const int64_t ldx,
+__global__ __launch_bounds__(NW4 * 64, NW4 / 4) void hiera_attn4_kernel(const half_t* __restrict__ h, float* __restrict__ x, const int64_t ldx,
                                                                    const half_t* __restrict__ img, const float* __restrict__ bias_g,
                                                                    const int Gh, const int Gw, const int nwin, const int ngroup,
                                                                    const float sl2) {
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(NW4 * 64, 2) void hiera_attn4_kernel(const half_t* 
 #pragma unroll
   for (int c = 0; c < LA4; ++c)
     if (c < ctotal) issue(c);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // bias: a raw s_barrier does not wait for this wave's LDS writes
+  __syncthreads();  // the biases are in LDS for every wave (the first reads come before the stream's first barrier)
 
   const int nWx = Gw >> 2, nWy = Gh >> 2;
   int c = 0;
@@ -553,4 +559,274 @@ extern "C" int lmx_k_hiera_attn4(const void* h, float* x, int64_t ldx, const voi
                      reinterpret_cast<const half_t*>(h), x, ldx, reinterpret_cast<const half_t*>(w_img), bias, Gh, Gw, (int)nwin, (int)ngroup,
                      scale * 1.44269504088896340736f);
   return lmx_launch_check("hiera_attn4_kernel");
+}
+
+// ================================================================================================================================
+// The block that opens stage 2 of Hiera-B+ (112 -> 224 channels, 4 heads of 56): keys and values are the 8 x 8 = 64 tokens of a
+// window, queries and the shortcut are their 2 x 2 max-pools (16 per window; TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock
+// .forward: `residual = do_pool(proj(hidden_states))`, Sam2MultiScaleAttention with q_stride: `query = do_pool(query)`), i.e. the five
+// launches shortcut GEMM (+ pool), q GEMM (+ pool), k | v GEMM, window attention with pooled queries, projection GEMM (+ residual).
+// One kernel, a wave per window, weights streamed as in hiera_attn4_kernel (14 images of 32 KB per pass of 8 windows).
+// The pooling costs nothing: the window's tokens are assigned to MFMA columns so that the four partners of a 2 x 2 pool sit in the
+// SAME lane of four different token blocks — block tb holds sub-position (tb >> 1, tb & 1) of pooled token fr — so a pool is an
+// element-wise maximum over four accumulator tiles and its result is already the 16-query operand / the 16-token output tile.
+// (max and the f16 rounding commute, so pooling the f32 accumulators equals pooling the rounded q as the unfused chain does.)
+namespace {
+
+#ifndef LMX_HP_NW
+#define LMX_HP_NW 8
+#endif
+#ifndef LMX_HP_V
+#define LMX_HP_V 0
+#endif
+constexpr int DI = 112, DO = 224, HEADSP = 4, KSP = 4, NWP = LMX_HP_NW, NIMG = 14;
+constexpr int NSTP = 4, LAP = NSTP - 1, PTP = MAT / (NWP * 1024);
+constexpr int NBP = DO + HEADSP * 192 + DO;  // biases: shortcut [224], [head][q | k | v][64], projection [224]
+constexpr int SMEMP = NSTP * MAT + NBP * 4;
+
+__device__ __forceinline__ f32x4 vmax4(const f32x4 a, const f32x4 b, const f32x4 c, const f32x4 d) {
+  return f32x4{fmaxf(fmaxf(a[0], b[0]), fmaxf(c[0], d[0])), fmaxf(fmaxf(a[1], b[1]), fmaxf(c[1], d[1])), fmaxf(fmaxf(a[2], b[2]), fmaxf(c[2], d[2])),
+               fmaxf(fmaxf(a[3], b[3]), fmaxf(c[3], d[3]))};
+}
+
+__global__ __launch_bounds__(NWP * 64, NWP / 4) void hiera_attnp_kernel(const half_t* __restrict__ h, float* __restrict__ out,
+                                                                         const half_t* __restrict__ img, const float* __restrict__ bias_g,
+                                                                         const int Gh, const int Gw, const int nwin, const int ngroup,
+                                                                         const float sl2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias = reinterpret_cast<float*>(smem + NSTP * MAT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int i = tid; i < NBP; i += NWP * 64) bias[i] = bias_g[i];
+
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(img), 0, NIMG * MAT, 0x00020000);
+  const int my_groups = (ngroup - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int ctotal = my_groups * NIMG;
+  const unsigned voff = (unsigned)(wave * (PTP * 1024) + lane * 16);
+  auto issue = [&](const int c) {
+    char* dst = smem + (c % NSTP) * MAT + wave * (PTP * 1024);
+#pragma unroll
+    for (int t = 0; t < PTP; ++t) lds_dma16(w_rs, dst + t * 1024, voff + t * 1024, (c % NIMG) * MAT);
+  };
+#pragma unroll
+  for (int c = 0; c < LAP; ++c)
+    if (c < ctotal) issue(c);
+  __syncthreads();  // the biases are in LDS for every wave
+
+  const int nWx = Gw >> 3, nWy = Gh >> 3, Go = Gw >> 1;
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  int c = 0;
+  for (int grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+    const int w = grp * NWP + wave;
+    const bool live = w < nwin;
+    const int wc = live ? w : 0;
+    const int im = wc / (nWy * nWx), wi = wc - im * (nWy * nWx);
+    const int wy = wi / nWx, wx = wi - wy * nWx;
+    // pooled token fr = (py, px) = (fr >> 2, fr & 3) of the window; block tb holds its partner (2 py + (tb >> 1), 2 px + (tb & 1))
+    half8_t xn[4][KSP];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      const int64_t row = ((int64_t)im * Gh + wy * 8 + 2 * (fr >> 2) + (tb >> 1)) * Gw + wx * 8 + 2 * (fr & 3) + (tb & 1);
+#pragma unroll
+      for (int ks = 0; ks < KSP; ++ks) {
+        const int d = ks * 32 + fg * 8;
+        const half8_t v = *reinterpret_cast<const half8_t*>(h + row * DI + (d < DI ? d : 0));
+        xn[tb][ks] = d < DI ? v : zero8;
+      }
+    }
+    auto step = [&]() -> const char* {
+      const int left = ctotal - 1 - c;
+      wait_tiles<PTP>(left < LAP - 1 ? left : LAP - 1);
+      __builtin_amdgcn_s_barrier();
+      if (c + LAP < ctotal) issue(c + LAP);
+      const char* m = smem + (c % NSTP) * MAT;
+      ++c;
+      return m;
+    };
+    // fragment of image rows row0 .. row0 + 15 (256-byte rows), k-step ks
+    auto frag = [&](const char* m, const int row0, const int ks) {
+      return *reinterpret_cast<const half8_t*>(m + (row0 + fr) * 256 + ((((ks << 2) + fg) ^ fr) << 4));
+    };
+
+    // ---- the shortcut: proj(h) pooled, + its bias + the output projection's bias: the accumulators of the block's output
+    f32x4 accp[14];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const char* m = step();
+#pragma unroll
+      for (int rb = half * 8; rb < (half ? 14 : 8); ++rb) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) {
+          const half8_t a = frag(m, (rb - half * 8) * 16, ks);
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[tb], 0, 0, 0);
+        }
+        accp[rb] = vmax4(acc[0], acc[1], acc[2], acc[3]) + *reinterpret_cast<const f32x4*>(bias + rb * 16 + fg * 4);  // shortcut + projection bias
+      }
+    }
+#pragma unroll 1
+    for (int hh = 0; hh < HEADSP; ++hh) {
+      const float* bh = bias + DO + hh * 192;
+      half8_t qf[2], kf[4][2];
+      {  // image [q | k] of the head: q^T pooled (16 queries), k^T (64 keys)
+        const char* m = step();
+#pragma unroll
+        for (int sec = 0; sec < 2; ++sec) {
+          f32x4 acc[4][4];
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < KSP; ++ks) {
+              const half8_t a = frag(m, sec * 64 + rb * 16, ks);
+#pragma unroll
+              for (int tb = 0; tb < 4; ++tb) acc[rb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[rb][tb], 0, 0, 0);
+            }
+          if (sec == 0) {
+            f32x4 qp[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              qp[rb] = vmax4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]) + *reinterpret_cast<const f32x4*>(bh + rb * 16 + fg * 4);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) qf[s] = pack8(qp[2 * s], qp[2 * s + 1]);
+          } else {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(bh + 64 + rb * 16 + fg * 4);
+#pragma unroll
+              for (int tb = 0; tb < 4; ++tb) acc[rb][tb] += bv;
+            }
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+              for (int s = 0; s < 2; ++s) kf[tb][s] = pack8(acc[2 * s][tb], acc[2 * s + 1][tb]);
+          }
+        }
+      }
+      half8_t of[2];
+      {  // image [v | -]: v [64 keys][64 d], then the head's attention: 16 pooled queries against the window's 64 keys
+        const char* m = step();
+        half8_t vf[4][2];
+        {
+          f32x4 acc[4][4];  // [token block][d block]
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            const float b = bh[128 + db * 16 + fr];
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[tb][db] = f32x4{b, b, b, b};
+          }
+#pragma unroll
+          for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int ks = 0; ks < KSP; ++ks) {
+              const half8_t bw = frag(m, db * 16, ks);
+#pragma unroll
+              for (int tb = 0; tb < 4; ++tb) acc[tb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb][db], 0, 0, 0);
+            }
+#pragma unroll
+          for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) vf[db][s] = pack8(acc[2 * s][db], acc[2 * s + 1][db]);
+        }
+        f32x4 sacc[4];  // S^T[key block][the 16 queries]
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 2; ++s) sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][s], qf[s], sacc[kb], 0, 0, 0);
+        }
+        float ma = hmax3(sacc[0][0], sacc[0][1], sacc[0][2]);
+        float mc = hmax3(sacc[2][0], sacc[2][1], sacc[2][2]);
+        ma = hmax3(ma, sacc[0][3], sacc[1][0]);
+        mc = hmax3(mc, sacc[2][3], sacc[3][0]);
+        ma = hmax3(ma, sacc[1][1], sacc[1][2]);
+        mc = hmax3(mc, sacc[3][1], sacc[3][2]);
+        ma = hmax3(ma, sacc[1][3], sacc[3][3]);
+#if LMX_HP_V == 1  // bisect build: the shuffle form of the cross-lane maximum
+        float mx_ = fmaxf(ma, mc);
+        mx_ = fmaxf(mx_, __shfl_xor(mx_, 16, 64));
+        mx_ = fmaxf(mx_, __shfl_xor(mx_, 32, 64));
+        const float nmb = -(mx_ * sl2);
+#else
+        const float nmb = -(hrow_max4(ma, mc) * sl2);
+#endif
+        f32x4 e[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[kb][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sl2, nmb));
+        half8_t pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) pf[s] = pack8(e[2 * s], e[2 * s + 1]);
+        f32x4 oacc[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 2; ++s) oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[db][s], pf[s], oacc[db], 0, 0, 0);
+        }
+        const float l = __shfl(oacc[3][3], 48 + fr, 64);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) of[s] = pack8(oacc[2 * s] * inv, oacc[2 * s + 1] * inv);
+      }
+      {  // image Wo[:, head]: 128-byte rows
+        const char* m = step();
+#pragma unroll
+        for (int ob = 0; ob < 14; ++ob)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(m + (ob * 16 + fr) * 128 + ((((s << 2) + fg) ^ ((fr >> 1) & 7)) << 4));
+            accp[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, of[s], accp[ob], 0, 0, 0);
+          }
+      }
+    }
+    if (live) {
+      const int64_t orow = ((int64_t)im * (Gh >> 1) + wy * 4 + (fr >> 2)) * Go + wx * 4 + (fr & 3);
+#pragma unroll
+      for (int ob = 0; ob < 14; ++ob) *reinterpret_cast<f32x4*>(out + orow * DO + ob * 16 + fg * 4) = accp[ob];
+    }
+  }
+}
+
+}  // namespace
+
+// h f16 [n_img * Gh * Gw, 112] contiguous = layer_norm1(x) on the (Gh x Gw) grid, Gh and Gw multiples of 8; out f32
+// [n_img * Gh/2 * Gw/2, 224] contiguous: the block's hidden state after the attention half, on the pooled grid.  w_img f16
+// [14][16384], bias f32 [224 + 4 * 192 + 224]: lmx/sam.py pack_hiera_attn_pool.
+extern "C" int lmx_k_hiera_attn_pool(const void* h, float* out, const void* w_img, const float* bias, int n_img, int Gh, int Gw, int Din,
+                                     int Dout, int heads, float scale, lmx_stream_t stream) {
+  LMX_REQUIRE(h && out && w_img && bias, "lmx_k_hiera_attn_pool: null pointer");
+  LMX_REQUIRE(Din == DI && Dout == DO && heads == HEADSP, "lmx_k_hiera_attn_pool: built for 112 -> 224 channels with 4 heads, got %d -> %d, %d heads",
+              Din, Dout, heads);
+  LMX_REQUIRE(n_img > 0 && Gh > 0 && Gw > 0 && Gh % 8 == 0 && Gw % 8 == 0, "lmx_k_hiera_attn_pool: token grid %d x %d is not whole 8 x 8 windows", Gh, Gw);
+  LMX_REQUIRE(aligned16(h) && aligned16(out) && aligned16(w_img), "lmx_k_hiera_attn_pool: alignment");
+  const int64_t nwin = (int64_t)n_img * (Gh / 8) * (Gw / 8);
+  LMX_REQUIRE(nwin < (1ll << 31), "lmx_k_hiera_attn_pool: too many windows");
+  const int64_t ngroup = (nwin + NWP - 1) / NWP;
+  static bool attr_set = false;
+  if (!attr_set) {
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_attnp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEMP));
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    LMX_HIP(hipGetDevice(&dev));
+    LMX_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const unsigned grid = (unsigned)(ngroup < n_cu ? ngroup : n_cu);
+  hipLaunchKernelGGL(hiera_attnp_kernel, dim3(grid), dim3(NWP * 64), SMEMP, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const half_t*>(h), out, reinterpret_cast<const half_t*>(w_img), bias, Gh, Gw, (int)nwin, (int)ngroup,
+                     scale * 1.44269504088896340736f);
+  return lmx_launch_check("hiera_attnp_kernel");
 }

@@ -323,6 +323,30 @@ def hiera_attn4(h, x, packed, n_img, Gh, Gw, heads):
     return x
 
 
+def hiera_attn_pool_ok(Din, Dout, heads, win, Gh, Gw, q_stride):
+    """Shapes lmx_k_hiera_attn_pool is built for: the block that opens Hiera-B+ stage 2 (112 -> 224, 4 heads, 8 x 8 windows, pooled queries)."""
+    return Din == 112 and Dout == 224 and heads == 4 and win == 8 and bool(q_stride) and Gh % 8 == 0 and Gw % 8 == 0 \
+        and os.environ.get("LMX_HIERA_ATTN_POOL", "1") != "0"
+
+
+def hiera_attn_pool(h, packed, n_img, Gh, Gw, heads, Dout):
+    """The attention half of Hiera's stage-opening block as one launch (csrc/hiera.hip): returns f32 [n*(Gh/2)*(Gw/2), Dout] =
+    pool(proj(h)) + attn_proj(window attention(pool(q(h)), k(h), v(h))).  h f16 [n*Gh*Gw, Din] contiguous = layer_norm1(x);
+    packed = (w_img, bias) from lmx.sam.pack_hiera_attn_pool."""
+    img, bias = packed
+    dev = _dev(h, img, bias)
+    if h.dtype != torch.float16 or h.dim() != 2 or not h.is_contiguous() or h.shape[0] != n_img * Gh * Gw:
+        raise LmxError("hiera_attn_pool: h must be contiguous float16 [n*Gh*Gw, Din]")
+    Din = h.shape[1]
+    if tuple(img.shape) != (14, 16384) or img.dtype != torch.float16 or not img.is_contiguous() or bias.numel() != 2 * Dout + heads * 192 \
+            or bias.dtype != torch.float32:
+        raise LmxError("hiera_attn_pool: packed operands have the wrong shapes (lmx.sam.pack_hiera_attn_pool)")
+    out = torch.empty((n_img * (Gh // 2) * (Gw // 2), Dout), dtype=torch.float32, device=h.device)
+    check(_lib.load().lmx_k_hiera_attn_pool(_ptr(h), _ptr(out), _ptr(img), _ptr(bias), n_img, Gh, Gw, Din, Dout, heads,
+                                            float((Dout // heads) ** -0.5), _stream(dev)), "lmx_k_hiera_attn_pool")
+    return out
+
+
 def _attn_desc(q, k, v, out, B, H, Tq, Tk, hd, scale, window, pad_k, pad_v):
     d = AttnDesc()
     d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()

@@ -177,6 +177,59 @@ def pack_hiera_attn4(wqkv, bqkv, wo, bo, heads):
     return img, bias
 
 
+def _lds_image(m, key):
+    """f16 matrix [rows, cols] (cols * 2 bytes = 128 or 256 per row) -> its LDS image: the 16-byte chunk c of row r stored at chunk
+    c ^ key(r); zero-padded to 32 KB."""
+    rows, cols = m.shape
+    ch = m.reshape(rows, cols // 8, 8)
+    out = np.zeros_like(ch)
+    for r in range(rows):
+        out[r, np.arange(cols // 8) ^ key(r)] = ch[r]
+    img = np.zeros((16384,), np.float16)
+    img[:rows * cols] = out.reshape(-1)
+    return img
+
+
+def pack_hiera_attn_pool(wsc, bsc, wqkv, bqkv, wo, bo, heads):
+    """Operands of lmx_k_hiera_attn_pool (csrc/hiera.hip) for the block that opens stage 2: wsc [Dout, Din] / bsc: the shortcut's
+    projection; wqkv [3 Dout, Din], bqkv; wo [Dout, Dout], bo (numpy, f32; Din 112, Dout 224, heads 4).  14 LDS images of 32 KB:
+    shortcut rows 0..127, shortcut rows 128.., then per head [q | k] (64 + 64 rows of 256 bytes, the head's 56 rows then zeros),
+    [v], and the projection's columns of the head (rows of 128 bytes in MFMA k-slot order); 256-byte rows are swizzled by r & 15,
+    128-byte rows by (r >> 1) & 7.  bias: shortcut [Dout], [head][q | k | v][64] (v's entry 63 is 1), projection [Dout]."""
+    Dout, Din = wsc.shape
+    hd = Dout // heads
+    k15, k7 = (lambda r: r & 15), (lambda r: (r >> 1) & 7)
+
+    def rows256(w):  # [rows, Din] -> f16 [rows, 128]
+        m = np.zeros((w.shape[0], 128), np.float16)
+        m[:, :Din] = w.astype(np.float16)
+        return m
+
+    imgs = [_lds_image(rows256(wsc[:128]), k15), _lds_image(rows256(np.concatenate([wsc[128:], np.zeros((256 - Dout, Din), np.float32)])), k15)]
+    bias = np.zeros((2 * Dout + heads * 192,), np.float32)
+    bias[:Dout] = bsc + bo  # the shortcut's and the output projection's biases: one vector, added once
+    for hh in range(heads):
+        sec = []
+        for s_ in range(3):
+            m = np.zeros((64, Din), np.float32)
+            m[:hd] = wqkv[s_ * Dout + hh * hd: s_ * Dout + (hh + 1) * hd]
+            sec.append(m)
+            bias[Dout + hh * 192 + s_ * 64: Dout + hh * 192 + s_ * 64 + hd] = bqkv[s_ * Dout + hh * hd: s_ * Dout + (hh + 1) * hd]
+        bias[Dout + hh * 192 + 128 + 63] = 1.0
+        imgs.append(_lds_image(rows256(np.concatenate(sec[:2])), k15))
+        imgs.append(_lds_image(rows256(sec[2]), k15))
+        m = np.zeros((256, 64), np.float16)
+        for s_ in range(2):
+            for g in range(4):
+                for hb in range(2):
+                    for i in range(4):
+                        d = 16 * (2 * s_ + hb) + 4 * g + i
+                        if d < hd:
+                            m[:Dout, 32 * s_ + 8 * g + 4 * hb + i] = wo[:, hh * hd + d].astype(np.float16)
+        imgs.append(_lds_image(m, k7))
+    return np.stack(imgs), bias  # (the last Dout entries stay zero: reserved)
+
+
 class HieraEncoder:
     """Device-resident Hiera trunk + FPN.  ``encode(frames)`` -> dict(fpn=[3 NHWC f16 levels, high->low res],
     stages=[4 f32 stage outputs]).  Token grids are [n, H, W, C] row-major throughout (no partition copies)."""
@@ -233,6 +286,11 @@ class HieraEncoder:
                 blk["attn4"] = tuple(torch.from_numpy(a).to(dev) for a in pack_hiera_attn4(
                     np.asarray(sd[p + "attn.qkv.weight"], np.float32), np.asarray(qkv_b, np.float32),
                     np.asarray(sd[p + "attn.proj.weight"], np.float32), np.asarray(sd[p + "attn.proj.bias"], np.float32), heads))
+            if dim == 112 and dim_out == 224 and heads == 4 and win_ == 8 and qs:  # the block that opens stage 2: pooled queries and shortcut
+                blk["attnp"] = tuple(torch.from_numpy(a).to(dev) for a in pack_hiera_attn_pool(
+                    np.asarray(sd[p + "proj.weight"], np.float32), np.asarray(sd[p + "proj.bias"], np.float32),
+                    np.asarray(sd[p + "attn.qkv.weight"], np.float32), np.asarray(qkv_b, np.float32),
+                    np.asarray(sd[p + "attn.proj.weight"], np.float32), np.asarray(sd[p + "attn.proj.bias"], np.float32), heads))
             self.blocks.append(blk)
         n = len(cfg.dims) - 1
         self.neck = [(t16(sd[f"neck.convs.{n - i}.weight"][:, :, 0, 0]), t32(sd[f"neck.convs.{n - i}.bias"])) for i in range(n + 1)]
@@ -281,6 +339,9 @@ class HieraEncoder:
                     K.hiera_attn8(x, B["attn8"], n, H, W, heads, ln=(B["g1"], B["b1"], cfg.eps))
                 else:
                     K.hiera_attn8(x, B["attn8"], n, H, W, heads, h=h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps))
+            elif "attnp" in B and K.hiera_attn_pool_ok(dim, D, heads, B["win"], H, W, qs):  # the stage-opening block: pooled q + shortcut
+                x = K.hiera_attn_pool(h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps), B["attnp"], n, H, W, heads, D)
+                H, W = H // 2, W // 2
             elif "attn4" in B and K.hiera_attn4_ok(D, heads, B["win"], H, W, qs):  # the same for 4 x 4 windows at D = 224
                 K.hiera_attn4(h_next if h_next is not None else K.layernorm(x, B["g1"], B["b1"], cfg.eps), x, B["attn4"], n, H, W, heads)
             else:
