@@ -101,6 +101,8 @@ def pmc_traffic_by_class():
             cls = "attention/mfma-bound"  # the LDS-DMA kernels: long flat sequences (Hiera's global blocks)
         elif "attn" in name:
             cls = "attention/hbm-bound"
+        elif "hiera_attn" in name:
+            cls = "fused attention half"
         elif "mlp_kernel" in name:  # (the summary truncates long mangled names from the left)
             cls = "fused ln+mlp"
         elif "layernorm" in name:

@@ -730,6 +730,20 @@ def _work(name, args):
     if name == "lmx_k_ln_mlp":
         rows, D = args[8], args[9]
         return "fused ln+mlp", 16.0 * D * D * rows, (16 + (2 if args[12] else 0) + (2 if args[15] else 0)) * D * rows, f"ln_mlp rows={rows} D={D}"
+    # the attention half of a Hiera block as one launch (csrc/hiera.hip): algorithmic flops of the unpadded products, bytes = the
+    # f32 stream read + written (+ the f16 LayerNorm rows where they are an input)
+    if name == "lmx_k_hiera_attn8":
+        n_, Gh, Gw, D = args[10], args[11], args[12], args[13]
+        rows = n_ * Gh * Gw
+        return "fused attention half", rows * (8.0 * D * D + 256.0 * D), rows * D * (8 + (2 if args[0] else 0)), f"hiera_attn8 rows={rows} D={D} ln_inside={int(not args[0])}"
+    if name == "lmx_k_hiera_attn4":
+        n_, Gh, Gw, D = args[5], args[6], args[7], args[8]
+        rows = n_ * Gh * Gw
+        return "fused attention half", rows * (8.0 * D * D + 64.0 * D), rows * D * 10, f"hiera_attn4 rows={rows} D={D}"
+    if name == "lmx_k_hiera_attn_pool":
+        n_, Gh, Gw, Di, Do = args[4], args[5], args[6], args[7], args[8]
+        rows = n_ * Gh * Gw
+        return "fused attention half", rows * (8.0 * Di * Do + 64.0 * Do + 0.5 * Do * Do), rows * (2 * Di + Do), f"hiera_attn_pool rows={rows} {Di}->{Do}"
     # streaming element-wise glue with a plain byte count: one HBM-bound class of its own (the rest — resizes, im2col, NMS,
     # mask_post, contour features, decode — stays "pre/post-processing and glue": time share only)
     if name == "lmx_k_cast_f32_f16":
