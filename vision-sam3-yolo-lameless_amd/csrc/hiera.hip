@@ -465,45 +465,47 @@ __global__ __launch_bounds__(NW4 * 64, NW4 / 4) void hiera_attn4_kernel(const ha
               kf[tb][s] = f;
           }
       }
+      // S^T[key][query] of each window and its softmax need no weights: done before v's image is consumed, so that q and k are dead
+      // by then.  Lane (query fr, fg) holds keys 4 fg .. 4 fg + 3.
+      half4v pf[TB4];
+#pragma unroll
+      for (int tb = 0; tb < TB4; ++tb) {
+        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[tb][s], qf[tb][s], sc, 0, 0, 0);
+        const float nmb = -(hrow_max4(__builtin_amdgcn_fmed3f(sc[0], sc[1], INFINITY), __builtin_amdgcn_fmed3f(sc[2], sc[3], INFINITY)) * sl2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf[tb][r] = (half_t)__builtin_amdgcn_exp2f(fmaf(sc[r], sl2, nmb));
+      }
       half8_t of[TB4][2];
-      {  // v: [16 tokens][64 d] per window (tokens are the MFMA rows), then the window's attention for this head
+      {  // v: [16 tokens][64 d] per window (tokens are the MFMA rows), one d block at a time, each straight into
+         // O^T[d][query] = V^T . P^T over the 16 keys: v_mfma_f32_16x16x16_f16, k-slot 4 g + i = key 4 g + i (both accumulator layouts)
         const char* m = step();
-        f32x4 acc[TB4][4];
+        f32x4 oacc[TB4][4];
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
           const float b = bias[hh * 192 + 128 + db * 16 + fr];
+          f32x4 acc[TB4];
 #pragma unroll
-          for (int tb = 0; tb < TB4; ++tb) acc[tb][db] = f32x4{b, b, b, b};
-        }
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
+          for (int tb = 0; tb < TB4; ++tb) acc[tb] = f32x4{b, b, b, b};
 #pragma unroll
           for (int ks = 0; ks < KS4; ++ks) {
             const half8_t bw = *reinterpret_cast<const half8_t*>(m + (db * 16 + fr) * 512 + ((((ks << 2) + fg) ^ fr) << 4));
 #pragma unroll
-            for (int tb = 0; tb < TB4; ++tb) acc[tb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb][db], 0, 0, 0);
+            for (int tb = 0; tb < TB4; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb], 0, 0, 0);
           }
+#pragma unroll
+          for (int tb = 0; tb < TB4; ++tb) {
+            const half4v vf = {(half_t)acc[tb][0], (half_t)acc[tb][1], (half_t)acc[tb][2], (half_t)acc[tb][3]};
+            oacc[tb][db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf[tb], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          }
+        }
 #pragma unroll
         for (int tb = 0; tb < TB4; ++tb) {
-          // S^T[key][query] of the window: lane (query fr, fg) holds keys 4 fg .. 4 fg + 3
-          f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < 2; ++s) sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[tb][s], qf[tb][s], sc, 0, 0, 0);
-          const float nmb = -(hrow_max4(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])) * sl2);
-          half4v pf;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pf[r] = (half_t)__builtin_amdgcn_exp2f(fmaf(sc[r], sl2, nmb));
-          // O^T[d][query] = V^T . P^T over the 16 keys: v_mfma_f32_16x16x16_f16, k-slot 4 g + i = key 4 g + i (both accumulator layouts)
-          f32x4 oacc[4];
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const half4v vf = {(half_t)acc[tb][db][0], (half_t)acc[tb][db][1], (half_t)acc[tb][db][2], (half_t)acc[tb][db][3]};
-            oacc[db] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          }
-          const float l = __shfl(oacc[3][3], 48 + fr, 64);  // row 63: the softmax sum (v's column 63 is the constant 1)
+          const float l = __shfl(oacc[tb][3][3], 48 + fr, 64);  // row 63: the softmax sum (v's column 63 is the constant 1)
           const float inv = 1.0f / l;
 #pragma unroll
-          for (int s = 0; s < 2; ++s) of[tb][s] = pack8(oacc[2 * s] * inv, oacc[2 * s + 1] * inv);
+          for (int s = 0; s < 2; ++s) of[tb][s] = pack8(oacc[tb][2 * s] * inv, oacc[tb][2 * s + 1] * inv);
         }
       }
       {  // x^T[o][token] += Wo[:, head hh] . O^T  (image rows of 128 B: 8 chunks, chunk c of row r at c ^ ((r >> 1) & 7))
@@ -575,9 +577,6 @@ namespace {
 
 #ifndef LMX_HP_NW
 #define LMX_HP_NW 8
-#endif
-#ifndef LMX_HP_V
-#define LMX_HP_V 0
 #endif
 constexpr int DI = 112, DO = 224, HEADSP = 4, KSP = 4, NWP = LMX_HP_NW, NIMG = 14;
 constexpr int NSTP = 4, LAP = NSTP - 1, PTP = MAT / (NWP * 1024);
@@ -671,70 +670,39 @@ __global__ __launch_bounds__(NWP * 64, NWP / 4) void hiera_attnp_kernel(const ha
 #pragma unroll 1
     for (int hh = 0; hh < HEADSP; ++hh) {
       const float* bh = bias + DO + hh * 192;
-      half8_t qf[2], kf[4][2];
-      {  // image [q | k] of the head: q^T pooled (16 queries), k^T (64 keys)
+      half8_t pf[2];  // P^T of the head: the 16 pooled queries against the 64 keys (k-slot order = key order of the v accumulators)
+      {  // image [q | k] of the head: q^T pooled (16 queries), k^T (64 keys); two row blocks (one k-step of S) at a time: 32 live
+         // accumulator registers instead of 64 (at 64 the kernel spilled, and the scratch traffic reached HBM: 1.3 GB written per
+         // launch for 0.44 GB of output, profiles/r03_pmc_summary.txt of the first build)
+        half8_t qf[2], kf[4][2];
         const char* m = step();
 #pragma unroll
-        for (int sec = 0; sec < 2; ++sec) {
-          f32x4 acc[4][4];
+        for (int sec = 0; sec < 2; ++sec)
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
+          for (int s = 0; s < 2; ++s) {
+            f32x4 acc[2][4];
 #pragma unroll
-            for (int tb = 0; tb < 4; ++tb) acc[rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
+              for (int tb = 0; tb < 4; ++tb) acc[r2][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KSP; ++ks) {
-              const half8_t a = frag(m, sec * 64 + rb * 16, ks);
+            for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-              for (int tb = 0; tb < 4; ++tb) acc[rb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[rb][tb], 0, 0, 0);
+              for (int ks = 0; ks < KSP; ++ks) {
+                const half8_t a = frag(m, sec * 64 + (2 * s + r2) * 16, ks);
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) acc[r2][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[r2][tb], 0, 0, 0);
+              }
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bh + sec * 64 + (2 * s) * 16 + fg * 4);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bh + sec * 64 + (2 * s + 1) * 16 + fg * 4);
+            if (sec == 0) {
+              qf[s] = pack8(vmax4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]) + b0, vmax4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]) + b1);
+            } else {
+#pragma unroll
+              for (int tb = 0; tb < 4; ++tb) kf[tb][s] = pack8(acc[0][tb] + b0, acc[1][tb] + b1);
             }
-          if (sec == 0) {
-            f32x4 qp[4];
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              qp[rb] = vmax4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]) + *reinterpret_cast<const f32x4*>(bh + rb * 16 + fg * 4);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) qf[s] = pack8(qp[2 * s], qp[2 * s + 1]);
-          } else {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(bh + 64 + rb * 16 + fg * 4);
-#pragma unroll
-              for (int tb = 0; tb < 4; ++tb) acc[rb][tb] += bv;
-            }
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-              for (int s = 0; s < 2; ++s) kf[tb][s] = pack8(acc[2 * s][tb], acc[2 * s + 1][tb]);
           }
-        }
-      }
-      half8_t of[2];
-      {  // image [v | -]: v [64 keys][64 d], then the head's attention: 16 pooled queries against the window's 64 keys
-        const char* m = step();
-        half8_t vf[4][2];
-        {
-          f32x4 acc[4][4];  // [token block][d block]
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const float b = bh[128 + db * 16 + fr];
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb) acc[tb][db] = f32x4{b, b, b, b};
-          }
-#pragma unroll
-          for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int ks = 0; ks < KSP; ++ks) {
-              const half8_t bw = frag(m, db * 16, ks);
-#pragma unroll
-              for (int tb = 0; tb < 4; ++tb) acc[tb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb][db], 0, 0, 0);
-            }
-#pragma unroll
-          for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) vf[db][s] = pack8(acc[2 * s][db], acc[2 * s + 1][db]);
-        }
+        // S and the softmax need no weights: done here, so that q and k are dead before v's image is consumed
         f32x4 sacc[4];  // S^T[key block][the 16 queries]
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -749,28 +717,33 @@ __global__ __launch_bounds__(NWP * 64, NWP / 4) void hiera_attnp_kernel(const ha
         ma = hmax3(ma, sacc[1][1], sacc[1][2]);
         mc = hmax3(mc, sacc[3][1], sacc[3][2]);
         ma = hmax3(ma, sacc[1][3], sacc[3][3]);
-#if LMX_HP_V == 1  // bisect build: the shuffle form of the cross-lane maximum
-        float mx_ = fmaxf(ma, mc);
-        mx_ = fmaxf(mx_, __shfl_xor(mx_, 16, 64));
-        mx_ = fmaxf(mx_, __shfl_xor(mx_, 32, 64));
-        const float nmb = -(mx_ * sl2);
-#else
         const float nmb = -(hrow_max4(ma, mc) * sl2);
-#endif
         f32x4 e[4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) e[kb][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sl2, nmb));
-        half8_t pf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) pf[s] = pack8(e[2 * s], e[2 * s + 1]);
-        f32x4 oacc[4];
+      }
+      half8_t of[2];
+      {  // image [v | -]: v [64 keys][64 d] one d block at a time, then the head's attention: 16 pooled queries against the window's 64 keys
+        const char* m = step();
+        f32x4 oacc[4];  // O^T[d block][the 16 queries]
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float b = bh[128 + db * 16 + fr];
+          f32x4 acc[4];  // v[token block][this d block]
 #pragma unroll
-          for (int s = 0; s < 2; ++s) oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[db][s], pf[s], oacc[db], 0, 0, 0);
+          for (int tb = 0; tb < 4; ++tb) acc[tb] = f32x4{b, b, b, b};
+#pragma unroll
+          for (int ks = 0; ks < KSP; ++ks) {
+            const half8_t bw = frag(m, db * 16, ks);
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb], 0, 0, 0);
+          }
+          oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(acc[0], acc[1]), pf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(acc[2], acc[3]), pf[1], oacc[db], 0, 0, 0);
         }
         const float l = __shfl(oacc[3][3], 48 + fr, 64);
         const float inv = 1.0f / l;
