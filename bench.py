@@ -93,7 +93,9 @@ def pmc_traffic_by_class():
         # the counters are per KERNEL NAME, the classes per launch (arithmetic intensity): the f32-output (residual-stream)
         # GEMM instantiations stand for the HBM-bound GEMM class, the f16-output ones for the MFMA-bound class — close, not
         # identical sets of launches (profiles/rNN_pmc_summary.txt has the per-kernel rows)
-        if "gemm2_kernel<1" in name or "gemm_kernel" in name and ", 1>" in name:
+        if "hiera_attn" in name:
+            cls = "fused attention half"
+        elif "gemm2_kernel<1" in name or "gemm_kernel" in name and ", 1>" in name:
             cls = "gemm/hbm-bound"      # f32-output (residual-stream) instantiations
         elif "gemm" in name:
             cls = "gemm/mfma-bound"
@@ -101,8 +103,6 @@ def pmc_traffic_by_class():
             cls = "attention/mfma-bound"  # the LDS-DMA kernels: long flat sequences (Hiera's global blocks)
         elif "attn" in name:
             cls = "attention/hbm-bound"
-        elif "hiera_attn" in name:
-            cls = "fused attention half"
         elif "mlp_kernel" in name:  # (the summary truncates long mangled names from the left)
             cls = "fused ln+mlp"
         elif "layernorm" in name:

@@ -1,5 +1,6 @@
 """Summarise the four rocprofv3 --pmc passes of tools/pmc.sh per kernel: launches, mean duration, HBM traffic per launch.
 FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md §HBM) and both counters are in KiB (rocprofv3 unit)."""
+import re
 import collections, csv, glob, json, sys
 
 def load(d):
@@ -23,7 +24,12 @@ def shorten(k):
         elif ch == "(" and depth == 0:
             break
         out.append(ch)
-    return "".join(out).strip()[-72:]
+    name = "".join(out).strip()
+    if name.startswith("_Z"):  # a mangled name rocprofv3 left alone: keep it from the kernel's own name on, not its last characters
+        m = re.search(r"\d+((?:ln_mlp|hiera_\w+?|im2col_u8|rope|stem_conv|cast|upsample2|hyper_mask)_?kernel\w*)", name)
+        if m:
+            return m.group(1)[:72]
+    return name[-72:]
 
 
 def main(root, out=None):
