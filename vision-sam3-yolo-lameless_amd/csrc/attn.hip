@@ -498,9 +498,11 @@ __device__ __forceinline__ float row_max4(float ma, float mc) {
 #endif
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <bool ONES>
-__global__ __launch_bounds__(256, 2) void attn_gp_kernel(const lmx_attn_desc p, const int nQT) {
-  constexpr int QB = 2, NSL = 3, RW = 64, PT = 4;
+// NWV waves share a K / V tile (64 * NWV / 2 ... 32 queries per wave): with 8 waves a wave issues ONE LDS-DMA piece per tensor and tile
+// instead of two (a piece costs the issuing wave 60 - 100 cycles beside MFMAs), at the price of a barrier among eight waves
+template <bool ONES, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void attn_gp_kernel(const lmx_attn_desc p, const int nQT) {
+  constexpr int QB = 2, NSL = 3, RW = 64, NJ = 8 / NWV, PT = 2 * NJ;  // NJ pieces per wave, tensor and tile (16 pieces of 8 rows per tile)
   // DYNAMIC LDS on purpose: for a static __shared__ array hipcc's waitcnt pass knows the LDS-DMA writes and the fragment reads
   // touch the same object and puts `s_waitcnt vmcnt(0)` in front of the first read after every issue — the ring then never has a
   // tile in flight (attn_kernel's DMA form has exactly that wait in its loop).  The counted waits below are the synchronisation.
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void attn_gp_kernel(const lmx_attn_desc p, 
   const int hd = p.hd;
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  const int q_base = qt * 128 + wave * 32;
+  const int q_base = qt * (NWV * 32) + wave * 32;
   half8_t qf[QB][2];
   int64_t qrow[QB];
 #pragma unroll
@@ -560,10 +562,10 @@ __global__ __launch_bounds__(256, 2) void attn_gp_kernel(const lmx_attn_desc p, 
       __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(K + (int64_t)b * p.Tk * p.ldk + (int64_t)h * hd), 0, (int)kbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t v_rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(V + (int64_t)b * p.Tk * p.ldv + (int64_t)h * hd), 0, (int)vbytes, 0x00020000);
-  unsigned kvo[2], vvo[2];
+  unsigned kvo[NJ], vvo[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (wave * 2 + j) * 8 + (lane >> 3);
+  for (int j = 0; j < NJ; ++j) {
+    const int row = (wave * NJ + j) * 8 + (lane >> 3);
     const int lc = (lane & 7) ^ (row & 7);
     const bool ok = lc * 8 < hd;
     kvo[j] = ok ? (unsigned)(row * (int)p.ldk * 2 + lc * 16) : 0x80000000u;
@@ -573,14 +575,14 @@ __global__ __launch_bounds__(256, 2) void attn_gp_kernel(const lmx_attn_desc p, 
   auto issue_k = [&](int it) {
     const unsigned ko = (unsigned)(it * 64 * (int)p.ldk * 2);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      lds_dma16(k_rs, reinterpret_cast<char*>(&Ks[it % NSL][0]) + (wave * 2 + j) * 1024, kvo[j] == 0x80000000u ? kvo[j] : kvo[j] + ko, 0);
+    for (int j = 0; j < NJ; ++j)
+      lds_dma16(k_rs, reinterpret_cast<char*>(&Ks[it % NSL][0]) + (wave * NJ + j) * 1024, kvo[j] == 0x80000000u ? kvo[j] : kvo[j] + ko, 0);
   };
   auto issue_v = [&](int it) {
     const unsigned vo = (unsigned)(it * 64 * (int)p.ldv * 2);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      lds_dma16(v_rs, reinterpret_cast<char*>(&Vs[it % NSL][0]) + (wave * 2 + j) * 1024, vvo[j] == 0x80000000u ? vvo[j] : vvo[j] + vo, 0);
+    for (int j = 0; j < NJ; ++j)
+      lds_dma16(v_rs, reinterpret_cast<char*>(&Vs[it % NSL][0]) + (wave * NJ + j) * 1024, vvo[j] == 0x80000000u ? vvo[j] : vvo[j] + vo, 0);
   };
   int k_lane[2], v_lane[4];
 #pragma unroll
@@ -615,9 +617,9 @@ __global__ __launch_bounds__(256, 2) void attn_gp_kernel(const lmx_attn_desc p, 
   if (ntile > 1) {
     issue_k(2);
     issue_v(1);
-    wait_vmcnt<8>();
+    wait_vmcnt<2 * PT>();
   } else {
-    wait_vmcnt<4>();
+    wait_vmcnt<PT>();
   }
   __builtin_amdgcn_s_barrier();
   f32x4 sA[QB][4], sB[QB][4];
@@ -1608,6 +1610,21 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   const bool dma = !no_dma && !wide && d.mode == 0 && !d.rel && big && d.Tk >= 256 && (int64_t)d.Tk * d.ldk * 2 < 0x7fff0000ll &&
                    (int64_t)d.Tk * d.ldv * 2 < 0x7fff0000ll;
   if (no_lazy) nQT = -nQT;
+  // the pipelined kernel runs 4 waves (128 queries) per workgroup; LMX_ATTN_GP_WAVES=8 selects the 8-wave form (256 queries share a
+  // K / V tile, one LDS-DMA piece per wave and tensor instead of two): measured SLOWER, 1595 vs 1526 us at B = 30, H = 8, T = 4096 —
+  // the barrier among eight waves costs more than the saved issue slots (identical bits)
+  static int gp_waves = -1;
+  if (gp_waves < 0) gp_waves = getenv("LMX_ATTN_GP_WAVES") ? atoi(getenv("LMX_ATTN_GP_WAVES")) : 4;
+  const bool gp8 = gp_waves == 8;
+  const int nQT8 = (d.Tq + 255) / 256;
+#define GP_LAUNCH(ones)                                                                                                                    \
+  do {                                                                                                                                     \
+    if (gp8)                                                                                                                               \
+      hipLaunchKernelGGL((attn_gp_kernel<ones, 8>), dim3((unsigned)((int64_t)d.B * d.H * nQT8)), dim3(512), 2 * 3 * 64 * 64 * 2, st, d,    \
+                         no_lazy ? -nQT8 : nQT8);                                                                                          \
+    else                                                                                                                                   \
+      hipLaunchKernelGGL((attn_gp_kernel<ones, 4>), dim3((unsigned)nblk), dim3(256), 2 * 3 * 64 * 64 * 2, st, d, nQT);                     \
+  } while (0)
   if (d.rel) {
     LMX_REQUIRE(d.rel_S > 0 && d.rel_S * d.rel_S == d.Tk && d.Tq == d.Tk, "lmx_k_attention: rel_S=%d does not match Tq=%d Tk=%d",
                 d.rel_S, d.Tq, d.Tk);
@@ -1620,9 +1637,9 @@ extern "C" int lmx_k_attention(const lmx_attn_desc* dp, lmx_stream_t stream) {
   } else if (wide)
     hipLaunchKernelGGL((attn_kernel<1, false, false, false, 96>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else if (dma && !no_gp && ones)
-    hipLaunchKernelGGL((attn_gp_kernel<true>), dim3((unsigned)nblk), dim3(256), 2 * 3 * 64 * 64 * 2, st, d, nQT);
+    GP_LAUNCH(true);
   else if (dma && !no_gp)
-    hipLaunchKernelGGL((attn_gp_kernel<false>), dim3((unsigned)nblk), dim3(256), 2 * 3 * 64 * 64 * 2, st, d, nQT);
+    GP_LAUNCH(false);
   else if (dma && ones)
     hipLaunchKernelGGL((attn_kernel<2, true, false, true, 64>), dim3((unsigned)nblk), dim3(256), 0, st, d, g, nQT);
   else if (dma)
