@@ -291,3 +291,35 @@ def test_mask_from_raw_frame_iou(cuda, kind, fixture):
     from lmx import kernels as K
     bits = K.pack_bits(out["mask"]).cpu().numpy()
     assert np.array_equal(np.unpackbits(bits, axis=-1)[:, :, :w].astype(bool), got)
+
+
+def test_hiera_fused_attention_halves_match_unfused_launches(cuda, monkeypatch):
+    """Hiera-B+ at 1024^2 with the attention halves of stages 1 - 2 as single kernels (csrc/hiera.hip: lmx_k_hiera_attn8 with and
+    without the LayerNorm inside, lmx_k_hiera_attn_pool, lmx_k_hiera_attn4) against the same encoder on the separate launches
+    they replace: every FPN level and stage output agrees to rounding (same rounding points, f32 sums in another order), and the
+    fused entry points are the ones that ran."""
+    from lmx import kernels as K
+    from lmx import sam, synth, weights
+
+    cfg = sam.hiera_b_plus()
+    enc = sam.HieraEncoder(cfg, weights.synth_state_dict(sam.param_spec(cfg), 5), cuda)
+    frames = torch.from_numpy(np.stack([synth.synth_frame(3, 40 + i) for i in range(2)], 0)).to(cuda)
+    K.start_launch_trace()
+    fused = enc.encode(frames)
+    torch.cuda.synchronize()
+    _, shapes = K.stop_launch_trace(by_shape=True)
+    ran = sorted(key.split()[0] + ("/ln" if "ln_inside=1" in key else "") for (cls, key) in shapes if cls == "fused attention half")
+    assert ran == ["hiera_attn4", "hiera_attn8", "hiera_attn8/ln", "hiera_attn_pool"], ran
+    assert sum(r["launches"] for (cls, _), r in shapes.items() if cls == "fused attention half") == 5  # blocks 0 - 4
+    for v in ("LMX_HIERA_ATTN8", "LMX_HIERA_ATTN4", "LMX_HIERA_ATTN_POOL"):
+        monkeypatch.setenv(v, "0")
+    K.start_launch_trace()
+    plain = enc.encode(frames)
+    torch.cuda.synchronize()
+    _, shapes = K.stop_launch_trace(by_shape=True)
+    assert not any(cls == "fused attention half" for (cls, _) in shapes)
+    for name in ("fpn", "stages"):
+        for lvl, (a, b) in enumerate(zip(fused[name], plain[name])):
+            rel, cos = _rel(a.float().cpu(), b.float().cpu())
+            print(f"fused vs unfused {name}[{lvl}]: rel {rel:.2e} cos-1 {cos - 1:.1e}")
+            assert rel < 2e-3 and cos > 1 - 1e-5, (name, lvl, rel, cos)

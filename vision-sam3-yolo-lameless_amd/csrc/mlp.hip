@@ -18,6 +18,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef LMX_MLP_DBG
+#define LMX_MLP_DBG 0
+#endif
 namespace lmx_mlp {
 
 constexpr int HC = 32;   // hidden units per chunk (one MFMA k-step of the second GEMM)
@@ -229,7 +232,8 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
         if (i + 2 < 2 * KS) ring[(i + 2) % 3] = w1read(i + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) sacc[qb][i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[i % 3], xn[qb][i >> 1], sacc[qb][i & 1], 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb)
+          if (LMX_MLP_DBG != 2 || rows < 0) sacc[qb][i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[i % 3], xn[qb][i >> 1], sacc[qb][i & 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -252,8 +256,13 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
     for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
+#if LMX_MLP_DBG == 1  // decomposition build: no GELU (wrong results)
+        const f32x2 g0 = f32x2{sacc[qb][hb][0], sacc[qb][hb][1]};
+        const f32x2 g1 = f32x2{sacc[qb][hb][2], sacc[qb][hb][3]};
+#else
         const f32x2 g0 = gelu_pk(f32x2{sacc[qb][hb][0], sacc[qb][hb][1]});
         const f32x2 g1 = gelu_pk(f32x2{sacc[qb][hb][2], sacc[qb][hb][3]});
+#endif
         pf[qb][4 * hb + 0] = (half_t)g0[0];
         pf[qb][4 * hb + 1] = (half_t)g0[1];
         pf[qb][4 * hb + 2] = (half_t)g1[0];
@@ -279,7 +288,8 @@ __global__ __launch_bounds__(NW * 64, OCC * NW / 4) void ln_mlp_kernel(float* __
         if (db + 2 < DB) ring[(db + 2) % 3] = w2read(db + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[db % 3], pf[qb], oacc[qb][db], 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb)
+          if (LMX_MLP_DBG != 3 || rows < 0) oacc[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[db % 3], pf[qb], oacc[qb][db], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
