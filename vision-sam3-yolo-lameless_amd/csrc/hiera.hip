@@ -175,107 +175,95 @@ __global__ __launch_bounds__(256, 1) void hiera_attn8_kernel(const half_t* __res
 
 #pragma unroll
     for (int hh = 0; hh < HEADS; ++hh) {
-      half8_t qf[4][2], kf[4][2], vf[4][2];
-      // ---- q^T and k^T: [64 d][64 tokens] each; rounded to f16 they are the B (q) and A (k) operands of S
+      // Live ranges are kept short on purpose (at their natural extent the kernel needed 463 registers and ~850 v_accvgpr moves):
+      // q and k two row blocks — one k-step of S — at a time, S and the softmax before v exists, v one d block at a time with its PV
+      // products issued at once.
+      half8_t pf[4][2];  // P^T[query block][k-step over keys]
+      {
+        half8_t qf[4][2], kf[4][2];
+        // ---- q^T and k^T: [64 d][64 tokens] each; rounded to f16 they are the B (q) and A (k) operands of S
 #pragma unroll
-      for (int sec = 0; sec < 2; ++sec) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int r0 = sec * (HEADS * HP) + hh * HP;
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + r0 + rb * 16 + fg * 4);
-#pragma unroll
-          for (int tb = 0; tb < 4; ++tb) acc[rb][tb] = bv;
-        }
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const half8_t a = wfrag(r0 + rb * 16, ks);
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb) acc[rb][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[rb][tb], 0, 0, 0);
-          }
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
+        for (int sec = 0; sec < 2; ++sec)
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            const half8_t f = pack8(acc[2 * s][tb], acc[2 * s + 1][tb]);
-            if (sec == 0)
-              qf[tb][s] = f;
-            else
-              kf[tb][s] = f;
+            const int r0 = sec * (HEADS * HP) + hh * HP + s * 32;
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + r0 + r2 * 16 + fg * 4);
+#pragma unroll
+              for (int tb = 0; tb < 4; ++tb) acc[r2][tb] = bv;
+            }
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+              for (int ks = 0; ks < KS; ++ks) {
+                const half8_t a = wfrag(r0 + r2 * 16, ks);
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) acc[r2][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[r2][tb], 0, 0, 0);
+              }
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) {
+              const half8_t f = pack8(acc[0][tb], acc[1][tb]);
+              if (sec == 0)
+                qf[tb][s] = f;
+              else
+                kf[tb][s] = f;
+            }
           }
-      }
-      __builtin_amdgcn_sched_barrier(0);  // phase boundary: nothing moves across (live ranges stay those of the phases)
-      // ---- v: [64 tokens][64 d] (tokens are the MFMA rows here); rounded, it is the A operand of PV (rows d, k-slots keys)
-      {
-        const int r0 = 2 * (HEADS * HP) + hh * HP;
-        f32x4 acc[4][4];  // [token block][d block]
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          const float b = bias[r0 + db * 16 + fr];
-#pragma unroll
-          for (int tb = 0; tb < 4; ++tb) acc[tb][db] = f32x4{b, b, b, b};
-        }
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const half8_t bw = wfrag(r0 + db * 16, ks);
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb) acc[tb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb][db], 0, 0, 0);
-          }
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int s = 0; s < 2; ++s) vf[db][s] = pack8(acc[2 * s][db], acc[2 * s + 1][db]);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // phase boundary: nothing moves across (live ranges stay those of the phases)
-      // ---- S^T[key][query] = K . Q^T, softmax over the 64 keys of a query (16 in this lane, 4 lanes per query)
-      half8_t pf[4][2];
-      {
-        f32x4 sacc[4][4];  // [key block][query block]
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int qb = 0; qb < 4; ++qb) {
-            sacc[kb][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) sacc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][s], qf[qb][s], sacc[kb][qb], 0, 0, 0);
-          }
+        // ---- S^T[key][query] = K . Q^T one query block at a time, softmax over the 64 keys of a query (16 in this lane, 4 lanes per query)
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
-          float ma = hmax3(sacc[0][qb][0], sacc[0][qb][1], sacc[0][qb][2]);
-          float mc = hmax3(sacc[2][qb][0], sacc[2][qb][1], sacc[2][qb][2]);
-          ma = hmax3(ma, sacc[0][qb][3], sacc[1][qb][0]);
-          mc = hmax3(mc, sacc[2][qb][3], sacc[3][qb][0]);
-          ma = hmax3(ma, sacc[1][qb][1], sacc[1][qb][2]);
-          mc = hmax3(mc, sacc[3][qb][1], sacc[3][qb][2]);
-          ma = hmax3(ma, sacc[1][qb][3], sacc[3][qb][3]);
+          f32x4 sacc[4];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][s], qf[qb][s], sacc[kb], 0, 0, 0);
+          }
+          float ma = hmax3(sacc[0][0], sacc[0][1], sacc[0][2]);
+          float mc = hmax3(sacc[2][0], sacc[2][1], sacc[2][2]);
+          ma = hmax3(ma, sacc[0][3], sacc[1][0]);
+          mc = hmax3(mc, sacc[2][3], sacc[3][0]);
+          ma = hmax3(ma, sacc[1][1], sacc[1][2]);
+          mc = hmax3(mc, sacc[3][1], sacc[3][2]);
+          ma = hmax3(ma, sacc[1][3], sacc[3][3]);
           const float nmb = -(hrow_max4(ma, mc) * sl2);
           f32x4 e[4];
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) e[kb][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][qb][r], sl2, nmb));
+            for (int r = 0; r < 4; ++r) e[kb][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sl2, nmb));
 #pragma unroll
           for (int s = 0; s < 2; ++s) pf[qb][s] = pack8(e[2 * s], e[2 * s + 1]);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);  // phase boundary: nothing moves across (live ranges stay those of the phases)
-      // ---- O^T[d][query] = V^T . P^T; row 63 is the softmax sum (v's column 63 is the constant 1); normalise, round
+      __builtin_amdgcn_sched_barrier(0);  // phase boundary: q and k are dead from here
+      // ---- v: [64 tokens][64 d] one d block at a time (tokens are the MFMA rows); rounded, it is the A operand of
+      // O^T[d][query] = V^T . P^T; row 63 of O^T is the softmax sum (v's column 63 is the constant 1); normalise, round
       half8_t of[4][2];
       {
+        const int r0 = 2 * (HEADS * HP) + hh * HP;
         f32x4 oacc[4][4];  // [d block][query block]
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < 4; ++db) {
+          const float b = bias[r0 + db * 16 + fr];
+          f32x4 acc[4];  // [token block]
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[tb] = f32x4{b, b, b, b};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const half8_t bw = wfrag(r0 + db * 16, ks);
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb], 0, 0, 0);
+          }
+          const half8_t v0 = pack8(acc[0], acc[1]), v1 = pack8(acc[2], acc[3]);
 #pragma unroll
           for (int qb = 0; qb < 4; ++qb) {
-            oacc[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) oacc[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[db][s], pf[qb][s], oacc[db][qb], 0, 0, 0);
+            oacc[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, pf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            oacc[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pf[qb][1], oacc[db][qb], 0, 0, 0);
           }
+        }
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
           const float l = __shfl(oacc[3][qb][3], 48 + fr, 64);  // O^T[63][query fr]: lane group 3, register 3 of d block 3
