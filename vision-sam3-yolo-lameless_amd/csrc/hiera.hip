@@ -7,10 +7,10 @@
 // bytes per token between them, of which only the f32 residual stream in and out (448 + 448) is algorithmic.
 //
 // How: a WAVE owns a window.  It reads the window's 64 f32 rows once — they are both the LayerNorm's input and the residual —,
-// normalises them in registers (a token's 112 features sit in four lanes), and the f16-rounded result is the register-resident
-// operand of every product; all weights
-// (q | k | v | proj: 124 KB as f16 with each head padded to 64 rows) sit in LDS for the life of the workgroup, and nothing a wave
-// computes is ever seen by another wave: no barrier, no exchange buffer, no LDS write after the prologue.
+// normalises them in registers (a token's 112 features sit in four lanes; or takes the f16 rows the previous block's fused MLP
+// left), and the f16-rounded result is the register-resident operand of every product; all weights (q | k | v | proj: 124 KB as
+// f16 with each head padded to 64 rows) sit in LDS for the life of the workgroup, and nothing a wave computes is ever seen by
+// another wave: no barrier, no exchange buffer, no LDS write after the prologue.
 //     q^T[d][t] = Wq . X^T     k^T[d][t] = Wk . X^T      (A = weight rows from LDS, B = the window's rows)
 //     v[t][d]   = X . Wv^T                               (A = the window's rows — the same registers —, B = weight rows from LDS)
 //     S^T[key][query] = K . Q^T                          (A and B are the f16-rounded accumulators of k^T and q^T)
@@ -27,7 +27,7 @@
 // (Tried on top and slower: weight fragments through a three-deep register ring with sched_barriers, 531 -> 699 us — hipcc's own
 // order, the next read issued behind four MFMAs that are still executing, hides most of the LDS latency —, and requesting the next
 // window's rows early, 799 us with spills.)
-// One wave per SIMD with the whole 512-register file (X 64, the projection's accumulators 112, q / k / v operands 96, S or O 64).
+// One wave per SIMD with the whole 512-register file (X 64, the projection's accumulators 112, P 32, O 64, short-lived tiles 16 - 32).
 #include "common.h"
 
 namespace {
