@@ -128,13 +128,16 @@ int lmx_k_hiera_attn8(const void* h, float* x, int64_t ldx, const float* gamma, 
 int lmx_k_hiera_attn4(const void* h, float* x, int64_t ldx, const void* w_img, const float* bias, int n_img, int Gh, int Gw, int D,
                       int heads, float scale, lmx_stream_t stream);
 
-/* The block that opens Hiera-B+ stage 2 (112 -> 224 channels, 4 heads of 56; keys / values the 64 tokens of an 8 x 8 window, queries
- * and shortcut their 2 x 2 max-pools; TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward with dim != dim_out and q_stride):
- * shortcut GEMM + pool, q GEMM + pool, k | v GEMM, window attention with pooled queries, projection GEMM + residual as one kernel
- * (csrc/hiera.hip; weights streamed).  h f16 [n_img*Gh*Gw, 112] contiguous = layer_norm1(x); out f32 [n_img*(Gh/2)*(Gw/2), 224]
- * contiguous (written, not accumulated); Gh, Gw multiples of 8.  w_img f16 [14][16384]: LDS images — shortcut rows 0..127,
- * shortcut rows 128..223, then per head [q | k] (2 x 64 rows of 256 B), [v | unused], projection columns of the head (256 rows of
- * 128 B, k-slot order) —, bias f32 [224 shortcut | 4 x (q | k | v) x 64 | 224 projection] (lmx/sam.py pack_hiera_attn_pool). */
+/* The blocks that open Hiera-B+ stage 2 (112 -> 224 channels, 4 heads of 56; keys / values the 64 tokens of an 8 x 8 window) and stage 3
+ * (224 -> 448, 8 heads; 16 tokens of a 4 x 4 window), queries and shortcut the 2 x 2 max-pools of the window's tokens
+ * (TF:models/sam2/modeling_sam2.py Sam2MultiScaleBlock.forward with dim != dim_out and q_stride): shortcut GEMM + pool, q GEMM + pool,
+ * k | v GEMM, window attention with pooled queries, projection GEMM + residual as one kernel (csrc/hiera.hip; weights streamed).
+ * h f16 [n_img*Gh*Gw, Din] contiguous = layer_norm1(x); out f32 [n_img*(Gh/2)*(Gw/2), Dout] contiguous (written, not accumulated);
+ * Gh, Gw multiples of the window side.  w_img f16 [14 | 47][16384]: LDS images in streaming order — 112 -> 224: shortcut rows
+ * 0..127, shortcut rows 128..223, then per head [q | k] (2 x 64 rows of 256 B), [v | unused], projection columns of the head (256
+ * rows of 128 B, k-slot order); 224 -> 448: shortcut in 7 images of 64 rows (512 B rows), then per head q, k, v (64 rows each) and
+ * the head's projection columns for output rows 0..223 and 224..447 —, bias f32 [shortcut + projection: Dout | heads x (q | k | v)
+ * x 64 (| Dout zeros for 112 -> 224)] (lmx/sam.py pack_hiera_attn_pool). */
 int lmx_k_hiera_attn_pool(const void* h, float* out, const void* w_img, const float* bias, int n_img, int Gh, int Gw, int Din, int Dout,
                           int heads, float scale, lmx_stream_t stream);
 

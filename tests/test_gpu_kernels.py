@@ -565,15 +565,18 @@ def test_hiera_attn4_fused_block(cuda, n, Gh, Gw):
     assert d < 4e-3
 
 
-@pytest.mark.parametrize("n,Gh,Gw", [(1, 8, 8), (1, 16, 24), (2, 64, 64), (3, 24, 40)])
-def test_hiera_attn_pool_fused_block(cuda, n, Gh, Gw):
-    """lmx_k_hiera_attn_pool (csrc/hiera.hip): the attention half of the block that opens Hiera stage 2 — pool(proj(h)) +
-    attn_proj(window attention(pool(q), k, v)), 112 -> 224 channels, 8 x 8 windows, 2 x 2 max-pooled queries and shortcut — against
-    the fp32 definition (TF sam2 Sam2MultiScaleBlock / Sam2MultiScaleAttention with q_stride) and the five launches it replaces."""
+@pytest.mark.parametrize("Din,D,heads,ws,n,Gh,Gw", [(112, 224, 4, 8, 1, 8, 8), (112, 224, 4, 8, 1, 16, 24), (112, 224, 4, 8, 2, 64, 64),
+                                                      (112, 224, 4, 8, 3, 24, 40), (224, 448, 8, 4, 1, 4, 4), (224, 448, 8, 4, 1, 8, 12),
+                                                      (224, 448, 8, 4, 2, 32, 32), (224, 448, 8, 4, 3, 20, 28)])
+def test_hiera_attn_pool_fused_block(cuda, Din, D, heads, ws, n, Gh, Gw):
+    """lmx_k_hiera_attn_pool (csrc/hiera.hip): the attention half of the blocks that open Hiera stages 2 and 3 — pool(proj(h)) +
+    attn_proj(window attention(pool(q), k, v)): 112 -> 224 channels on 8 x 8 windows, 224 -> 448 on 4 x 4 windows, 2 x 2 max-pooled
+    queries and shortcut — against the fp32 definition (TF sam2 Sam2MultiScaleBlock / Sam2MultiScaleAttention with q_stride) and the
+    five launches it replaces.  The grids cover single windows, partial last groups and several groups per workgroup."""
     from lmx import kernels as Kk
     from lmx import sam
 
-    Din, D, heads, hd = 112, 224, 4, 56
+    hd, wq = D // heads, ws // 2
     rows = n * Gh * Gw
     h = _rand((rows, Din), 91, 1.0).half()
     wsc = (_rand((D, Din), 92, 1.0) * Din ** -0.5).half().float()
@@ -590,15 +593,15 @@ def test_hiera_attn_pool_fused_block(cuda, n, Gh, Gw):
     sc = pool((hf @ wsc.t() + bsc).view(n, Gh, Gw, D))
     qkv = (hf @ wqkv.t() + bqkv).view(n, Gh, Gw, 3, D)
     q = pool(qkv[..., 0, :])  # [n, Gh/2, Gw/2, D]
-    q = q.reshape(n, Gh // 8, 4, Gw // 8, 4, heads, hd).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, heads, 16, hd)
-    kk, vv = (qkv[..., j, :].reshape(n, Gh // 8, 8, Gw // 8, 8, heads, hd).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, heads, 64, hd) for j in (1, 2))
-    att = torch.softmax(q @ kk.transpose(-1, -2) * hd ** -0.5, -1) @ vv  # [windows, heads, 16, hd]
-    att = att.view(n, Gh // 8, Gw // 8, heads, 4, 4, hd).permute(0, 1, 4, 2, 5, 3, 6).reshape(n, Gh // 2, Gw // 2, D)
+    q = q.reshape(n, Gh // ws, wq, Gw // ws, wq, heads, hd).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, heads, wq * wq, hd)
+    kk, vv = (qkv[..., j, :].reshape(n, Gh // ws, ws, Gw // ws, ws, heads, hd).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, heads, ws * ws, hd) for j in (1, 2))
+    att = torch.softmax(q @ kk.transpose(-1, -2) * hd ** -0.5, -1) @ vv  # [windows, heads, wq * wq, hd]
+    att = att.view(n, Gh // ws, Gw // ws, heads, wq, wq, hd).permute(0, 1, 4, 2, 5, 3, 6).reshape(n, Gh // 2, Gw // 2, D)
     ref = (sc + att @ wo.t() + bo).reshape(-1, D)
     packed = tuple(torch.from_numpy(a).to(cuda) for a in sam.pack_hiera_attn_pool(wsc.numpy(), bsc.numpy(), wqkv.numpy(), bqkv.numpy(), wo.numpy(),
                                                                                   bo.numpy(), heads))
     out = Kk.hiera_attn_pool(h.to(cuda), packed, n, Gh, Gw, heads, D)
-    _close(out, ref, 4e-3, 4e-3, f"hiera_attn_pool n{n} {Gh}x{Gw} vs fp32")
+    _close(out, ref, 4e-3, 4e-3, f"hiera_attn_pool {Din}->{D} n{n} {Gh}x{Gw} vs fp32")
     # the unfused launches (as lmx/sam.py HieraEncoder._attention_half runs them)
     hd_ = h.to(cuda)
     scu = Kk.gemm(hd_, wsc.half().to(cuda), bias=bsc.to(cuda), out_dtype=torch.float32)
@@ -608,11 +611,11 @@ def test_hiera_attn_pool_fused_block(cuda, n, Gh, Gw):
     qp = torch.empty((n, Gh // 2, Gw // 2, D), dtype=torch.float16, device=cuda)
     Kk.maxpool2(q3.view(n, Gh, Gw, 3 * D)[..., :D], qp)
     a = torch.empty((rows // 4, D), dtype=torch.float16, device=cuda)
-    Kk.attention(qp.view(-1, D), q3[:, D:2 * D], q3[:, 2 * D:], a, n * (Gh // 8) * (Gw // 8), heads, 16, 64, hd, hd ** -0.5,
-                 window=dict(Gh=Gh, Gw=Gw, ws=8, q_stride=2), pad_k=q3[0, D:2 * D].contiguous(), pad_v=q3[0, 2 * D:].contiguous())
+    Kk.attention(qp.view(-1, D), q3[:, D:2 * D], q3[:, 2 * D:], a, n * (Gh // ws) * (Gw // ws), heads, wq * wq, ws * ws, hd, hd ** -0.5,
+                 window=dict(Gh=Gh, Gw=Gw, ws=ws, q_stride=2), pad_k=q3[0, D:2 * D].contiguous(), pad_v=q3[0, 2 * D:].contiguous())
     xu = torch.empty((rows // 4, D), dtype=torch.float32, device=cuda)
     Kk.gemm(a, wo.half().to(cuda), bias=bo.to(cuda), res=pooled.view(-1, D), out=xu)
     d = (out - xu).abs().max().item()
-    print(f"hiera_attn_pool n{n} {Gh}x{Gw}: max |fused - unfused| {d:.3e}, max |fused - fp32| {(out.cpu() - ref).abs().max().item():.3e}, "
+    print(f"hiera_attn_pool {Din}->{D} n{n} {Gh}x{Gw}: max |fused - unfused| {d:.3e}, max |fused - fp32| {(out.cpu() - ref).abs().max().item():.3e}, "
           f"max |unfused - fp32| {(xu.cpu() - ref).abs().max().item():.3e}")
     assert d < 4e-3

@@ -294,8 +294,9 @@ def test_mask_from_raw_frame_iou(cuda, kind, fixture):
 
 
 def test_hiera_fused_attention_halves_match_unfused_launches(cuda, monkeypatch):
-    """Hiera-B+ at 1024^2 with the attention halves of stages 1 - 2 as single kernels (csrc/hiera.hip: lmx_k_hiera_attn8 with and
-    without the LayerNorm inside, lmx_k_hiera_attn_pool, lmx_k_hiera_attn4) against the same encoder on the separate launches
+    """Hiera-B+ at 1024^2 with the attention halves of stages 1 - 2 and of the block that opens stage 3 as single kernels
+    (csrc/hiera.hip: lmx_k_hiera_attn8 with and without the LayerNorm inside, lmx_k_hiera_attn_pool in both shapes, lmx_k_hiera_attn4)
+    against the same encoder on the separate launches
     they replace: every FPN level and stage output agrees to rounding (same rounding points, f32 sums in another order), and the
     fused entry points are the ones that ran."""
     from lmx import kernels as K
@@ -309,8 +310,8 @@ def test_hiera_fused_attention_halves_match_unfused_launches(cuda, monkeypatch):
     torch.cuda.synchronize()
     _, shapes = K.stop_launch_trace(by_shape=True)
     ran = sorted(key.split()[0] + ("/ln" if "ln_inside=1" in key else "") for (cls, key) in shapes if cls == "fused attention half")
-    assert ran == ["hiera_attn4", "hiera_attn8", "hiera_attn8/ln", "hiera_attn_pool"], ran
-    assert sum(r["launches"] for (cls, _), r in shapes.items() if cls == "fused attention half") == 5  # blocks 0 - 4
+    assert ran == ["hiera_attn4", "hiera_attn8", "hiera_attn8/ln", "hiera_attn_pool", "hiera_attn_pool"], ran  # (the pool form: stages 2 and 3)
+    assert sum(r["launches"] for (cls, _), r in shapes.items() if cls == "fused attention half") == 6  # blocks 0 - 5
     for v in ("LMX_HIERA_ATTN8", "LMX_HIERA_ATTN4", "LMX_HIERA_ATTN_POOL"):
         monkeypatch.setenv(v, "0")
     K.start_launch_trace()

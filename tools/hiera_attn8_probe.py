@@ -106,3 +106,36 @@ for n, G in ((30, 256), (10, 256)):
     t_f = timeit(lambda: K.hiera_attn_pool(h, packedp, n, G, G, heads, D), iters=5)
     print(f"stage-opening block, {n} frames: unfused (shortcut, q, kv GEMMs + window attention + proj GEMM) {t_u * 1e3:.0f} us, fused {t_f * 1e3:.0f} us "
           f"({(rows * 224 + rows // 4 * 896) / t_f / 1e9:.2f} TB/s algorithmic)", flush=True)
+
+# the block that opens stage 3: 224 -> 448 channels, 4 x 4 windows, pooled queries and shortcut
+Din, D, heads, hd = 224, 448, 8, 56
+for n, G in ((30, 128), (10, 128)):
+    rows = n * G * G
+    g = torch.Generator().manual_seed(8)
+    h = torch.randn((rows, Din), generator=g).half().to(dev)
+    wsc = (torch.randn((D, Din), generator=g) * Din ** -0.5).half().float()
+    bsc = torch.randn((D,), generator=g) * 0.2
+    wqkv = (torch.randn((3 * D, Din), generator=g) * Din ** -0.5).half().float()
+    bqkv = torch.randn((3 * D,), generator=g) * 0.2
+    wo = (torch.randn((D, D), generator=g) * D ** -0.5).half().float()
+    bo = torch.randn((D,), generator=g) * 0.2
+    packedq = tuple(torch.from_numpy(a).to(dev) for a in sam.pack_hiera_attn_pool(wsc.numpy(), bsc.numpy(), wqkv.numpy(), bqkv.numpy(), wo.numpy(),
+                                                                                   bo.numpy(), heads))
+    wsc16, w16, wo16 = wsc.half().to(dev), wqkv.half().to(dev), wo.half().to(dev)
+    bscd, bq, bod = bsc.to(dev), bqkv.to(dev), bo.to(dev)
+    a = torch.empty((rows // 4, D), dtype=torch.float16, device=dev)
+    xo = torch.empty((rows // 4, D), dtype=torch.float32, device=dev)
+    pk, pv = torch.zeros(D, dtype=torch.float16, device=dev), torch.zeros(D, dtype=torch.float16, device=dev)
+
+    def unfusedq():
+        sc = K.gemm(h, wsc16, bias=bscd, out_dtype=torch.float32, pool_hw=(G, G))
+        q = K.gemm(h, w16[:D], bias=bq[:D], pool_hw=(G, G))
+        kv = K.gemm(h, w16[D:], bias=bq[D:])
+        K.attention(q, kv[:, :D], kv[:, D:], a, n * (G // 4) ** 2, heads, 4, 16, hd, hd ** -0.5,
+                    window=dict(Gh=G, Gw=G, ws=4, q_stride=2), pad_k=pk, pad_v=pv)
+        K.gemm(a, wo16, bias=bod, res=sc, out=xo)
+
+    t_u = timeit(unfusedq, iters=5)
+    t_f = timeit(lambda: K.hiera_attn_pool(h, packedq, n, G, G, heads, D), iters=5)
+    print(f"stage-3 opener, {n} frames: unfused (shortcut, q, kv GEMMs + window attention + proj GEMM) {t_u * 1e3:.0f} us, fused {t_f * 1e3:.0f} us "
+          f"({(rows * 448 + rows // 4 * 1792) / t_f / 1e9:.2f} TB/s algorithmic)", flush=True)

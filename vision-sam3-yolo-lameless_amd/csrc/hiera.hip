@@ -759,22 +759,225 @@ __global__ __launch_bounds__(NWP * 64, NWP / 4) void hiera_attnp_kernel(const ha
 
 }  // namespace
 
-// h f16 [n_img * Gh * Gw, 112] contiguous = layer_norm1(x) on the (Gh x Gw) grid, Gh and Gw multiples of 8; out f32
-// [n_img * Gh/2 * Gw/2, 224] contiguous: the block's hidden state after the attention half, on the pooled grid.  w_img f16
-// [14][16384], bias f32 [224 + 4 * 192 + 224]: lmx/sam.py pack_hiera_attn_pool.
+// ================================================================================================================================
+// The block that opens stage 3 (224 -> 448 channels, 8 heads of 56): the same operation on 4 x 4-token windows — 16 keys / values, 4
+// pooled queries and shortcut rows per window.  A wave takes FOUR windows: lane fr is pooled token fr & 3 of window fr >> 2, block tb
+// its 2 x 2 partner (tb >> 1, tb & 1), so the pools are again element-wise maxima and the 16 pooled tokens of the four windows form
+// one MFMA block.  The four windows share the S and PV tiles: S^T[key][query] holds the products of every key with every query of
+// the four windows, and a lane keeps only those of its own window — key rows 4 fg .. 4 fg + 3 of a block belong to window fg,
+// query fr to window fr >> 2 — the others are set to -inf before the softmax (P = 0: they drop out of PV and of the row sum).
+// 47 weight images per pass (shortcut 7, per head q, k, v and two halves of the projection's columns), 4 waves with the whole
+// register file (X alone is 112 registers, the output accumulators another 112; hipcc spills ~150 registers per lane, all of it in
+// the per-group prologue / shortcut / epilogue code — none inside the head loop).
+namespace {
+
+constexpr int DI2 = 224, DO2 = 448, HEADS2 = 8, KS2 = 7, NW2 = 4, NIMG2 = 7 + 5 * HEADS2;
+constexpr int NST2 = 4, LA2 = NST2 - 1, PT2 = MAT / (NW2 * 1024);
+constexpr int NB2 = DO2 + HEADS2 * 192;  // biases: shortcut + projection [448], [head][q | k | v][64]
+constexpr int SMEM2 = NST2 * MAT + NB2 * 4;
+
+__global__ __launch_bounds__(NW2 * 64, 1) void hiera_attnq_kernel(const half_t* __restrict__ h, float* __restrict__ out,
+                                                                   const half_t* __restrict__ img, const float* __restrict__ bias_g,
+                                                                   const int Gh, const int Gw, const int nwin, const int ngroup,
+                                                                   const float sl2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias = reinterpret_cast<float*>(smem + NST2 * MAT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int i = tid; i < NB2; i += NW2 * 64) bias[i] = bias_g[i];
+
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(img), 0, NIMG2 * MAT, 0x00020000);
+  const int my_groups = (ngroup - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int ctotal = my_groups * NIMG2;
+  const unsigned voff = (unsigned)(wave * (PT2 * 1024) + lane * 16);
+  auto issue = [&](const int c) {
+    char* dst = smem + (c % NST2) * MAT + wave * (PT2 * 1024);
+#pragma unroll
+    for (int t = 0; t < PT2; ++t) lds_dma16(w_rs, dst + t * 1024, voff + t * 1024, (c % NIMG2) * MAT);
+  };
+#pragma unroll
+  for (int c = 0; c < LA2; ++c)
+    if (c < ctotal) issue(c);
+  __syncthreads();  // the biases are in LDS for every wave
+
+  const int nWx = Gw >> 2, nWy = Gh >> 2, Go = Gw >> 1;
+  const bool mine = fg == (fr >> 2);  // S^T rows of this lane (keys of window fg) against its query's window
+  int c = 0;
+  for (int grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+    const int w = grp * (NW2 * 4) + wave * 4 + (fr >> 2);
+    const bool live = w < nwin;
+    const int wc = live ? w : 0;
+    const int im = wc / (nWy * nWx), wi = wc - im * (nWy * nWx);
+    const int wy = wi / nWx, wx = wi - wy * nWx;
+    const int py = (fr >> 1) & 1, px = fr & 1;
+    half8_t xn[4][KS2];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      const int64_t row = ((int64_t)im * Gh + wy * 4 + 2 * py + (tb >> 1)) * Gw + wx * 4 + 2 * px + (tb & 1);
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) xn[tb][ks] = *reinterpret_cast<const half8_t*>(h + row * DI2 + ks * 32 + fg * 8);
+    }
+    auto step = [&]() -> const char* {
+      const int left = ctotal - 1 - c;
+      wait_tiles<PT2>(left < LA2 - 1 ? left : LA2 - 1);
+      __builtin_amdgcn_s_barrier();
+      if (c + LA2 < ctotal) issue(c + LA2);
+      const char* m = smem + (c % NST2) * MAT;
+      ++c;
+      return m;
+    };
+    auto frag = [&](const char* m, const int row0, const int ks) {  // 512-byte rows
+      return *reinterpret_cast<const half8_t*>(m + (row0 + fr) * 512 + ((((ks << 2) + fg) ^ fr) << 4));
+    };
+
+    // ---- the shortcut: proj(h) pooled (+ its bias + the output projection's): the accumulators of the block's output
+    f32x4 accp[28];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const char* m = step();
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int rb = j * 4 + r4;
+        f32x4 acc[4];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+          const half8_t a = frag(m, r4 * 16, ks);
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[tb], 0, 0, 0);
+        }
+        accp[rb] = vmax4(acc[0], acc[1], acc[2], acc[3]) + *reinterpret_cast<const f32x4*>(bias + rb * 16 + fg * 4);
+      }
+    }
+#pragma unroll 1
+    for (int hh = 0; hh < HEADS2; ++hh) {
+      const float* bh = bias + DO2 + hh * 192;
+      half8_t pf[2];
+      {
+        half8_t qf[2], kf[4][2];
+#pragma unroll
+        for (int sec = 0; sec < 2; ++sec) {  // image q, then image k of the head
+          const char* m = step();
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+              for (int tb = 0; tb < 4; ++tb) acc[r2][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+              for (int ks = 0; ks < KS2; ++ks) {
+                const half8_t a = frag(m, (2 * s + r2) * 16, ks);
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) acc[r2][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[r2][tb], 0, 0, 0);
+              }
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bh + sec * 64 + (2 * s) * 16 + fg * 4);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bh + sec * 64 + (2 * s + 1) * 16 + fg * 4);
+            if (sec == 0) {
+              qf[s] = pack8(vmax4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]) + b0, vmax4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]) + b1);
+            } else {
+#pragma unroll
+              for (int tb = 0; tb < 4; ++tb) kf[tb][s] = pack8(acc[0][tb] + b0, acc[1][tb] + b1);
+            }
+          }
+        }
+        // S^T[key block][16 queries of four windows]; a lane keeps its own window's keys
+        f32x4 sacc[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 2; ++s) sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][s], qf[s], sacc[kb], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[kb][r] = mine ? sacc[kb][r] : -INFINITY;
+        }
+        float ma = hmax3(sacc[0][0], sacc[0][1], sacc[0][2]);
+        float mc = hmax3(sacc[2][0], sacc[2][1], sacc[2][2]);
+        ma = hmax3(ma, sacc[0][3], sacc[1][0]);
+        mc = hmax3(mc, sacc[2][3], sacc[3][0]);
+        ma = hmax3(ma, sacc[1][1], sacc[1][2]);
+        mc = hmax3(mc, sacc[3][1], sacc[3][2]);
+        ma = hmax3(ma, sacc[1][3], sacc[3][3]);
+        const float nmb = -(hrow_max4(ma, mc) * sl2);
+        f32x4 e[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[kb][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sl2, nmb));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) pf[s] = pack8(e[2 * s], e[2 * s + 1]);
+      }
+      half8_t of[2];
+      {  // image v: one d block at a time, each straight into O^T
+        const char* m = step();
+        f32x4 oacc[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const float b = bh[128 + db * 16 + fr];
+          f32x4 acc[4];
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[tb] = f32x4{b, b, b, b};
+#pragma unroll
+          for (int ks = 0; ks < KS2; ++ks) {
+            const half8_t bw = frag(m, db * 16, ks);
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xn[tb][ks], bw, acc[tb], 0, 0, 0);
+          }
+          oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(acc[0], acc[1]), pf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(acc[2], acc[3]), pf[1], oacc[db], 0, 0, 0);
+        }
+        const float l = __shfl(oacc[3][3], 48 + fr, 64);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) of[s] = pack8(oacc[2 * s] * inv, oacc[2 * s + 1] * inv);
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {  // the projection's columns of the head, output rows 0..223 then 224..447 (128-byte rows)
+        const char* m = step();
+#pragma unroll
+        for (int o14 = 0; o14 < 14; ++o14)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(m + (o14 * 16 + fr) * 128 + ((((s << 2) + fg) ^ ((fr >> 1) & 7)) << 4));
+            accp[half * 14 + o14] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, of[s], accp[half * 14 + o14], 0, 0, 0);
+          }
+      }
+    }
+    if (live) {
+      const int64_t orow = ((int64_t)im * (Gh >> 1) + wy * 2 + py) * Go + wx * 2 + px;
+#pragma unroll
+      for (int ob = 0; ob < 28; ++ob) *reinterpret_cast<f32x4*>(out + orow * DO2 + ob * 16 + fg * 4) = accp[ob];
+    }
+  }
+}
+
+}  // namespace
+
+// h f16 [n_img * Gh * Gw, Din] contiguous = layer_norm1(x) on the (Gh x Gw) grid; out f32 [n_img * Gh/2 * Gw/2, Dout] contiguous: the
+// block's hidden state after the attention half, on the pooled grid.  112 -> 224 (4 heads, 8 x 8 windows: Gh, Gw multiples of 8):
+// w_img f16 [14][16384], bias f32 [224 + 4 * 192 + 224]; 224 -> 448 (8 heads, 4 x 4 windows): w_img [47][16384], bias [448 + 8 * 192]
+// (lmx/sam.py pack_hiera_attn_pool).
 extern "C" int lmx_k_hiera_attn_pool(const void* h, float* out, const void* w_img, const float* bias, int n_img, int Gh, int Gw, int Din,
                                      int Dout, int heads, float scale, lmx_stream_t stream) {
   LMX_REQUIRE(h && out && w_img && bias, "lmx_k_hiera_attn_pool: null pointer");
-  LMX_REQUIRE(Din == DI && Dout == DO && heads == HEADSP, "lmx_k_hiera_attn_pool: built for 112 -> 224 channels with 4 heads, got %d -> %d, %d heads",
-              Din, Dout, heads);
-  LMX_REQUIRE(n_img > 0 && Gh > 0 && Gw > 0 && Gh % 8 == 0 && Gw % 8 == 0, "lmx_k_hiera_attn_pool: token grid %d x %d is not whole 8 x 8 windows", Gh, Gw);
+  const bool s3 = Din == DI2 && Dout == DO2 && heads == HEADS2;  // the block that opens stage 3: 4 x 4 windows
+  LMX_REQUIRE(s3 || (Din == DI && Dout == DO && heads == HEADSP),
+              "lmx_k_hiera_attn_pool: built for 112 -> 224 channels with 4 heads and 224 -> 448 with 8, got %d -> %d, %d heads", Din, Dout, heads);
+  const int ws = s3 ? 4 : 8;
+  LMX_REQUIRE(n_img > 0 && Gh > 0 && Gw > 0 && Gh % ws == 0 && Gw % ws == 0, "lmx_k_hiera_attn_pool: token grid %d x %d is not whole %d x %d windows", Gh, Gw, ws, ws);
   LMX_REQUIRE(aligned16(h) && aligned16(out) && aligned16(w_img), "lmx_k_hiera_attn_pool: alignment");
-  const int64_t nwin = (int64_t)n_img * (Gh / 8) * (Gw / 8);
+  const int64_t nwin = (int64_t)n_img * (Gh / ws) * (Gw / ws);
   LMX_REQUIRE(nwin < (1ll << 31), "lmx_k_hiera_attn_pool: too many windows");
-  const int64_t ngroup = (nwin + NWP - 1) / NWP;
+  const int per = s3 ? NW2 * 4 : NWP;  // windows per workgroup pass
+  const int64_t ngroup = (nwin + per - 1) / per;
   static bool attr_set = false;
   if (!attr_set) {
     LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_attnp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEMP));
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_attnq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2));
     attr_set = true;
   }
   static int n_cu = 0;
@@ -786,8 +989,13 @@ extern "C" int lmx_k_hiera_attn_pool(const void* h, float* out, const void* w_im
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const unsigned grid = (unsigned)(ngroup < n_cu ? ngroup : n_cu);
-  hipLaunchKernelGGL(hiera_attnp_kernel, dim3(grid), dim3(NWP * 64), SMEMP, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const half_t*>(h), out, reinterpret_cast<const half_t*>(w_img), bias, Gh, Gw, (int)nwin, (int)ngroup,
-                     scale * 1.44269504088896340736f);
-  return lmx_launch_check("hiera_attnp_kernel");
+  if (s3)
+    hipLaunchKernelGGL(hiera_attnq_kernel, dim3(grid), dim3(NW2 * 64), SMEM2, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const half_t*>(h), out, reinterpret_cast<const half_t*>(w_img), bias, Gh, Gw, (int)nwin, (int)ngroup,
+                       scale * 1.44269504088896340736f);
+  else
+    hipLaunchKernelGGL(hiera_attnp_kernel, dim3(grid), dim3(NWP * 64), SMEMP, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const half_t*>(h), out, reinterpret_cast<const half_t*>(w_img), bias, Gh, Gw, (int)nwin, (int)ngroup,
+                       scale * 1.44269504088896340736f);
+  return lmx_launch_check("hiera_attn_pool kernel");
 }

@@ -324,9 +324,15 @@ def hiera_attn4(h, x, packed, n_img, Gh, Gw, heads):
 
 
 def hiera_attn_pool_ok(Din, Dout, heads, win, Gh, Gw, q_stride):
-    """Shapes lmx_k_hiera_attn_pool is built for: the block that opens Hiera-B+ stage 2 (112 -> 224, 4 heads, 8 x 8 windows, pooled queries)."""
-    return Din == 112 and Dout == 224 and heads == 4 and win == 8 and bool(q_stride) and Gh % 8 == 0 and Gw % 8 == 0 \
-        and os.environ.get("LMX_HIERA_ATTN_POOL", "1") != "0"
+    """Shapes lmx_k_hiera_attn_pool is built for: the blocks that open Hiera-B+ stage 2 (112 -> 224, 4 heads, 8 x 8 windows) and
+    stage 3 (224 -> 448, 8 heads, 4 x 4 windows), pooled queries and shortcut."""
+    if not q_stride or os.environ.get("LMX_HIERA_ATTN_POOL", "1") == "0":
+        return False
+    if (Din, Dout, heads, win) == (112, 224, 4, 8):
+        return Gh % 8 == 0 and Gw % 8 == 0
+    if (Din, Dout, heads, win) == (224, 448, 8, 4):  # the block that opens stage 3 (LMX_HIERA_ATTN_POOL3=0: its separate launches)
+        return Gh % 4 == 0 and Gw % 4 == 0 and os.environ.get("LMX_HIERA_ATTN_POOL3", "1") != "0"
+    return False
 
 
 def hiera_attn_pool(h, packed, n_img, Gh, Gw, heads, Dout):
@@ -338,8 +344,8 @@ def hiera_attn_pool(h, packed, n_img, Gh, Gw, heads, Dout):
     if h.dtype != torch.float16 or h.dim() != 2 or not h.is_contiguous() or h.shape[0] != n_img * Gh * Gw:
         raise LmxError("hiera_attn_pool: h must be contiguous float16 [n*Gh*Gw, Din]")
     Din = h.shape[1]
-    if tuple(img.shape) != (14, 16384) or img.dtype != torch.float16 or not img.is_contiguous() or bias.numel() != 2 * Dout + heads * 192 \
-            or bias.dtype != torch.float32:
+    nimg, nb = (47, Dout + heads * 192) if Din > 128 else (14, 2 * Dout + heads * 192)
+    if tuple(img.shape) != (nimg, 16384) or img.dtype != torch.float16 or not img.is_contiguous() or bias.numel() != nb or bias.dtype != torch.float32:
         raise LmxError("hiera_attn_pool: packed operands have the wrong shapes (lmx.sam.pack_hiera_attn_pool)")
     out = torch.empty((n_img * (Gh // 2) * (Gw // 2), Dout), dtype=torch.float32, device=h.device)
     check(_lib.load().lmx_k_hiera_attn_pool(_ptr(h), _ptr(out), _ptr(img), _ptr(bias), n_img, Gh, Gw, Din, Dout, heads,
@@ -743,7 +749,8 @@ def _work(name, args):
     if name == "lmx_k_hiera_attn_pool":
         n_, Gh, Gw, Di, Do = args[4], args[5], args[6], args[7], args[8]
         rows = n_ * Gh * Gw
-        return "fused attention half", rows * (8.0 * Di * Do + 64.0 * Do + 0.5 * Do * Do), rows * (2 * Di + Do), f"hiera_attn_pool rows={rows} {Di}->{Do}"
+        keys = 64 if Di == 112 else 16  # tokens of a window
+        return "fused attention half", rows * (8.0 * Di * Do + keys * Do + 0.5 * Do * Do), rows * (2 * Di + Do), f"hiera_attn_pool rows={rows} {Di}->{Do}"
     # streaming element-wise glue with a plain byte count: one HBM-bound class of its own (the rest — resizes, im2col, NMS,
     # mask_post, contour features, decode — stays "pre/post-processing and glue": time share only)
     if name == "lmx_k_cast_f32_f16":

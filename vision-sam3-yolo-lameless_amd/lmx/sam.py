@@ -191,34 +191,43 @@ def _lds_image(m, key):
 
 
 def pack_hiera_attn_pool(wsc, bsc, wqkv, bqkv, wo, bo, heads):
-    """Operands of lmx_k_hiera_attn_pool (csrc/hiera.hip) for the block that opens stage 2: wsc [Dout, Din] / bsc: the shortcut's
-    projection; wqkv [3 Dout, Din], bqkv; wo [Dout, Dout], bo (numpy, f32; Din 112, Dout 224, heads 4).  14 LDS images of 32 KB:
-    shortcut rows 0..127, shortcut rows 128.., then per head [q | k] (64 + 64 rows of 256 bytes, the head's 56 rows then zeros),
-    [v], and the projection's columns of the head (rows of 128 bytes in MFMA k-slot order); 256-byte rows are swizzled by r & 15,
-    128-byte rows by (r >> 1) & 7.  bias: shortcut [Dout], [head][q | k | v][64] (v's entry 63 is 1), projection [Dout]."""
+    """Operands of lmx_k_hiera_attn_pool (csrc/hiera.hip) for a block that opens a stage: wsc [Dout, Din] / bsc: the shortcut's
+    projection; wqkv [3 Dout, Din], bqkv; wo [Dout, Dout], bo (numpy, f32).  LDS images of 32 KB, in the order the kernel streams them.
+    Din 112 -> Dout 224 (4 heads): 14 images — shortcut rows 0..127, shortcut rows 128.., then per head [q | k] (64 + 64 rows of 256
+    bytes, the head's 56 rows then zeros), [v], and the projection's columns of the head (rows of 128 bytes in MFMA k-slot order).
+    Din 224 -> Dout 448 (8 heads): 47 images — shortcut in 7 images of 64 rows (512-byte rows), then per head q, k, v (64 rows each) and
+    the projection's columns of the head in two images (output rows 0..223, 224..447).  Rows of 256 / 512 bytes are swizzled by r & 15,
+    rows of 128 bytes by (r >> 1) & 7.  bias: shortcut + projection [Dout], [head][q | k | v][64] (v's entry 63 is 1)[, Dout zeros]."""
     Dout, Din = wsc.shape
     hd = Dout // heads
+    wide = Din > 128  # 512-byte rows
+    cols = 256 if wide else 128
     k15, k7 = (lambda r: r & 15), (lambda r: (r >> 1) & 7)
 
-    def rows256(w):  # [rows, Din] -> f16 [rows, 128]
-        m = np.zeros((w.shape[0], 128), np.float16)
-        m[:, :Din] = w.astype(np.float16)
-        return m
+    def rows_img(w, nrows):  # [<= nrows, Din] -> image of nrows rows of `cols` halfs
+        m = np.zeros((nrows, cols), np.float16)
+        m[:w.shape[0], :Din] = w.astype(np.float16)
+        return _lds_image(m, k15)
 
-    imgs = [_lds_image(rows256(wsc[:128]), k15), _lds_image(rows256(np.concatenate([wsc[128:], np.zeros((256 - Dout, Din), np.float32)])), k15)]
-    bias = np.zeros((2 * Dout + heads * 192,), np.float32)
+    if wide:
+        imgs = [rows_img(wsc[64 * j: 64 * j + 64], 64) for j in range(7)]
+    else:
+        imgs = [rows_img(wsc[:128], 128), rows_img(wsc[128:], 128)]
+    bias = np.zeros((Dout + heads * 192 + (0 if wide else Dout),), np.float32)
     bias[:Dout] = bsc + bo  # the shortcut's and the output projection's biases: one vector, added once
     for hh in range(heads):
         sec = []
         for s_ in range(3):
-            m = np.zeros((64, Din), np.float32)
-            m[:hd] = wqkv[s_ * Dout + hh * hd: s_ * Dout + (hh + 1) * hd]
-            sec.append(m)
+            sec.append(wqkv[s_ * Dout + hh * hd: s_ * Dout + (hh + 1) * hd])
             bias[Dout + hh * 192 + s_ * 64: Dout + hh * 192 + s_ * 64 + hd] = bqkv[s_ * Dout + hh * hd: s_ * Dout + (hh + 1) * hd]
         bias[Dout + hh * 192 + 128 + 63] = 1.0
-        imgs.append(_lds_image(rows256(np.concatenate(sec[:2])), k15))
-        imgs.append(_lds_image(rows256(sec[2]), k15))
-        m = np.zeros((256, 64), np.float16)
+        if wide:
+            imgs += [rows_img(sec[0], 64), rows_img(sec[1], 64), rows_img(sec[2], 64)]
+        else:
+            qk = np.zeros((128, Din), np.float32)
+            qk[:hd], qk[64:64 + hd] = sec[0], sec[1]
+            imgs += [rows_img(qk, 128), rows_img(sec[2], 64)]
+        m = np.zeros((512 if wide else 256, 64), np.float16)
         for s_ in range(2):
             for g in range(4):
                 for hb in range(2):
@@ -226,8 +235,14 @@ def pack_hiera_attn_pool(wsc, bsc, wqkv, bqkv, wo, bo, heads):
                         d = 16 * (2 * s_ + hb) + 4 * g + i
                         if d < hd:
                             m[:Dout, 32 * s_ + 8 * g + 4 * hb + i] = wo[:, hh * hd + d].astype(np.float16)
-        imgs.append(_lds_image(m, k7))
-    return np.stack(imgs), bias  # (the last Dout entries stay zero: reserved)
+        if wide:
+            for half in range(2):
+                mm = np.zeros((256, 64), np.float16)
+                mm[:224] = m[224 * half: 224 * half + 224]
+                imgs.append(_lds_image(mm, k7))
+        else:
+            imgs.append(_lds_image(m, k7))
+    return np.stack(imgs), bias
 
 
 class HieraEncoder:
@@ -286,7 +301,7 @@ class HieraEncoder:
                 blk["attn4"] = tuple(torch.from_numpy(a).to(dev) for a in pack_hiera_attn4(
                     np.asarray(sd[p + "attn.qkv.weight"], np.float32), np.asarray(qkv_b, np.float32),
                     np.asarray(sd[p + "attn.proj.weight"], np.float32), np.asarray(sd[p + "attn.proj.bias"], np.float32), heads))
-            if dim == 112 and dim_out == 224 and heads == 4 and win_ == 8 and qs:  # the block that opens stage 2: pooled queries and shortcut
+            if qs and ((dim, dim_out, heads, win_) in ((112, 224, 4, 8), (224, 448, 8, 4))):  # the blocks that open stages 2 and 3: pooled queries and shortcut
                 blk["attnp"] = tuple(torch.from_numpy(a).to(dev) for a in pack_hiera_attn_pool(
                     np.asarray(sd[p + "proj.weight"], np.float32), np.asarray(sd[p + "proj.bias"], np.float32),
                     np.asarray(sd[p + "attn.qkv.weight"], np.float32), np.asarray(qkv_b, np.float32),
