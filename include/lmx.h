@@ -152,6 +152,15 @@ int lmx_k_hiera_attn_pool(const void* h, float* out, const void* w_img, const fl
 int lmx_k_ln_mlp(float* x, int64_t ldx, const float* gamma, const float* beta, const void* w1, const float* b1,
                  const void* w2, const float* b2, int64_t rows, int D, float eps, void* workspace, void* x16,
                  const float* gamma_next, const float* beta_next, void* h_next, lmx_stream_t stream);
+/* The same operation with the weights as host-made LDS images streamed in steps of 64 hidden units by a workgroup of 8 waves x 32
+ * tokens (csrc/hiera.hip hiera_mlp_kernel: half the L2 -> LDS traffic and a quarter to a half of the barriers of the kernel above;
+ * layer_norm2 always inside).  w_img f16 [7 | 28][16384] for D = 112 | 224: per step the 64 rows of W1 (256 | 512-byte rows, the D
+ * input columns in MFMA k-slot order, chunk c of row r at c ^ (r & 15)) and the D rows x 64 columns of W2 (128-byte rows, columns
+ * in k-slot order, chunk c of row r at c ^ ((r >> 1) & 7); D = 112: in the same image at byte 16384, D = 224: the next image);
+ * bias f32 [b1 (4D) | b2 | gamma2 | beta2 | gamma_next | beta_next (D each; the last two unused without h_next)] (lmx/sam.py
+ * pack_ln_mlp).  x16, h_next: as below. */
+int lmx_k_ln_mlp_img(float* x, int64_t ldx, const void* w_img, const float* bias, int64_t rows, int D, float eps, void* x16, void* h_next,
+                     lmx_stream_t stream);
 /* x16: NULL, or f16 [rows, D] (contiguous) that receives a copy of the updated x — the input of the FPN's lateral 1x1
  * convolution after a stage's last block, which otherwise costs a cast pass over the f32 stream.
  * h_next: NULL, or f16 [rows, D] that receives LayerNorm(updated x; gamma_next, beta_next, eps) — the NEXT block's

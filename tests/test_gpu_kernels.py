@@ -619,3 +619,42 @@ def test_hiera_attn_pool_fused_block(cuda, Din, D, heads, ws, n, Gh, Gw):
     print(f"hiera_attn_pool {Din}->{D} n{n} {Gh}x{Gw}: max |fused - unfused| {d:.3e}, max |fused - fp32| {(out.cpu() - ref).abs().max().item():.3e}, "
           f"max |unfused - fp32| {(xu.cpu() - ref).abs().max().item():.3e}")
     assert d < 4e-3
+
+
+@pytest.mark.parametrize("D,rows", [(112, 256), (112, 5000), (224, 300), (224, 70000)])
+def test_ln_mlp_img(cuda, D, rows):
+    """lmx_k_ln_mlp_img (csrc/hiera.hip hiera_mlp_kernel): x += fc2(gelu(fc1(LayerNorm(x)))) with the weights streamed as LDS images,
+    with the f16 copy and the next block's LayerNorm rows, against the fp32 definition and against lmx_k_ln_mlp (csrc/mlp.hip: same
+    rounding points).  Row counts cover a partial last group of 256 tokens and several groups per workgroup."""
+    from lmx import kernels as Kk
+    from lmx import sam
+
+    x = _rand((rows, D), 101, 1.0) + 0.2
+    g2, e2 = 1.0 + _rand((D,), 102, 0.2), _rand((D,), 103, 0.2)
+    gn, en = 1.0 + _rand((D,), 104, 0.2), _rand((D,), 105, 0.2)
+    w1 = (_rand((4 * D, D), 106, 1.0) * D ** -0.5).half().float()
+    b1 = _rand((4 * D,), 107, 0.2)
+    w2 = (_rand((D, 4 * D), 108, 1.0) * (4 * D) ** -0.5).half().float()
+    b2 = _rand((D,), 109, 0.2)
+    eps = 1e-6
+    hh = torch.nn.functional.layer_norm(x, (D,), g2, e2, eps)
+    ref = x + torch.nn.functional.gelu(hh @ w1.t() + b1) @ w2.t() + b2
+    refn = torch.nn.functional.layer_norm(ref, (D,), gn, en, eps)
+    packed = tuple(torch.from_numpy(a).to(cuda) for a in sam.pack_ln_mlp(w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), g2.numpy(), e2.numpy(),
+                                                                         gn.numpy(), en.numpy()))
+    xd = x.to(cuda)
+    x16 = torch.zeros((rows, D), dtype=torch.float16, device=cuda)
+    hn = torch.zeros((rows, D), dtype=torch.float16, device=cuda)
+    Kk.ln_mlp_img(xd, packed, eps, x16=x16, h_next=hn)
+    _close(xd, ref, 4e-3, 4e-3, f"ln_mlp_img D{D} rows{rows} vs fp32")
+    _close(hn, refn, 6e-3, 6e-3, f"ln_mlp_img D{D} rows{rows} h_next vs fp32")
+    assert torch.equal(x16, xd.half())
+    xu = x.to(cuda)
+    x16u = torch.zeros_like(x16)
+    hnu = torch.zeros_like(hn)
+    Kk.ln_mlp(xu, g2.to(cuda), e2.to(cuda), w1.half().to(cuda), b1.to(cuda), w2.half().to(cuda), b2.to(cuda), eps, x16=x16u,
+              next_ln=(gn.to(cuda), en.to(cuda), hnu))
+    d = (xd - xu).abs().max().item()
+    print(f"ln_mlp_img D{D} rows{rows}: max |img - mlp.hip| {d:.3e}, max |img - fp32| {(xd.cpu() - ref).abs().max().item():.3e}, "
+          f"max |mlp.hip - fp32| {(xu.cpu() - ref).abs().max().item():.3e}")
+    assert d < 4e-3

@@ -999,3 +999,254 @@ extern "C" int lmx_k_hiera_attn_pool(const void* h, float* out, const void* w_im
                        scale * 1.44269504088896340736f);
   return lmx_launch_check("hiera_attn_pool kernel");
 }
+
+// ================================================================================================================================
+// The MLP half of the same blocks in the same form (round 3): x += fc2(gelu(fc1(layer_norm2(x)))) for D = 112 / 224 with the weights
+// streamed as host-made LDS images in steps of 64 hidden units.  What csrc/mlp.hip's kernel (which this replaces for these widths)
+// pays for: it streams all 8 D^2 bytes of weights through LDS per 128 tokens in 32-unit chunks — 3.4 GB of L2 -> LDS traffic per
+// 30-frame launch at either width, a barrier per 28 - 30 MFMAs of a wave (profiles/r03_fused_mlp_decompose.txt: two thirds of its
+// time is that fixed cost).  Here a workgroup is 8 waves x 32 (D = 224) or 48 (D = 112) tokens per pass over the weights and a step
+// is 56 - 90 MFMAs per wave.  It pays from a few hundred thousand rows: 1123 -> 966 us at 1.97 M rows of D = 112, 825 -> 736 us at
+// 491 520 rows of D = 224 (tools/mlp_probe.py, with the next block's LayerNorm output), but 346 -> 401 and 236 -> 314 us at a third
+// of those rows — 256 persistent workgroups with 3 - 7 passes each start and drain badly — so lmx/sam.py keeps csrc/mlp.hip's kernel
+// for the small batches of the reference schedule.  A wave reads its 32 f32 rows once in accumulator layout (lane (token fr, fg) holds features 16 ob + 4 fg .. + 3):
+// they are layer_norm2's input (statistics over the four lanes of a token), and + b2 the initial fc2 accumulators; the normalised
+// rows, rounded to f16, are fc1's B operand in k-slot order (W1's columns are stored in that order), fc1's GELU'd accumulators are
+// fc2's B operand (W2's columns of a step likewise).  Outputs as lmx_k_ln_mlp: x in place, optionally its f16 copy and the next
+// block's layer_norm1 rows.  Rounding points as in csrc/mlp.hip (LayerNorm output and GELU output f16, sums f32, rsq for the
+// LayerNorm's 1 / sqrt).
+namespace {
+
+template <int DD>
+struct MlpCfg {
+  static constexpr int KS = (DD + 31) / 32;            // k-steps over the token width (112 -> 4, the last one half empty)
+  static constexpr int OB = DD / 16;                   // 16-feature blocks of a row
+  static constexpr int NCH = 4 * DD / 64;              // steps of 64 hidden units
+  static constexpr bool ONE = DD <= 128;               // W1 step (64 rows x 256 B) and W2 step (DD rows x 128 B) share one 32 KB image
+  static constexpr int NIMG = ONE ? NCH : 2 * NCH;
+  static constexpr int ROW1 = DD <= 128 ? 256 : 512;   // bytes per W1 image row
+  static constexpr int NB = 4 * DD + 5 * DD;           // b1 [4D], b2 [D], gamma2, beta2, gamma_next, beta_next [D each]
+};
+#ifndef LMX_MLP_TB112
+#define LMX_MLP_TB112 3  // measured at 1.97 M rows: 2 blocks 1006 us, 3 blocks 966 us, 4 blocks 998 us (csrc/mlp.hip: 1123 - 1173 us)
+#endif
+constexpr int NWM = 8, NSTM = 4, LAM = NSTM - 1, PTM = MAT / (NWM * 1024);
+template <int DD>
+constexpr int mlp_tb() { return DD == 112 ? LMX_MLP_TB112 : 2; }  // 16-token blocks per wave
+
+template <int DD>
+__global__ __launch_bounds__(NWM * 64, 2) void hiera_mlp_kernel(float* __restrict__ x, const int64_t ldx, const half_t* __restrict__ img,
+                                                                 const float* __restrict__ bias_g, const float eps, const int64_t rows,
+                                                                 half_t* __restrict__ x16, half_t* __restrict__ h_n, const int ngroup) {
+  using C = MlpCfg<DD>;
+  constexpr int KS = C::KS, OB = C::OB, TBM = mlp_tb<DD>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias = reinterpret_cast<float*>(smem + NSTM * MAT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int i = tid; i < C::NB; i += NWM * 64) bias[i] = bias_g[i];
+  const float* b1s = bias;
+  const float* b2s = bias + 4 * DD;
+  const float* g2s = bias + 5 * DD;
+  const float* e2s = bias + 6 * DD;
+  const float* gns = bias + 7 * DD;
+  const float* ens = bias + 8 * DD;
+
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(img), 0, C::NIMG * MAT, 0x00020000);
+  const int my_groups = (ngroup - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int ctotal = my_groups * C::NIMG;
+  const unsigned voff = (unsigned)(wave * (PTM * 1024) + lane * 16);
+  auto issue = [&](const int c) {
+    char* dst = smem + (c % NSTM) * MAT + wave * (PTM * 1024);
+#pragma unroll
+    for (int t = 0; t < PTM; ++t) lds_dma16(w_rs, dst + t * 1024, voff + t * 1024, (c % C::NIMG) * MAT);
+  };
+#pragma unroll
+  for (int c = 0; c < LAM; ++c)
+    if (c < ctotal) issue(c);
+  __syncthreads();  // the biases and LayerNorm vectors are in LDS for every wave
+
+  int c = 0;
+  for (int grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+    int64_t trow[TBM];
+    bool live[TBM];
+#pragma unroll
+    for (int tb = 0; tb < TBM; ++tb) {
+      const int64_t t = (int64_t)grp * (NWM * TBM * 16) + wave * (TBM * 16) + tb * 16 + fr;
+      live[tb] = t < rows;
+      trow[tb] = live[tb] ? t : 0;
+    }
+    // the rows in accumulator layout; layer_norm2 over the four lanes of a token
+    f32x4 oacc[OB][TBM];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int tb = 0; tb < TBM; ++tb) oacc[ob][tb] = *reinterpret_cast<const f32x4*>(x + trow[tb] * ldx + ob * 16 + fg * 4);
+    half8_t xn[TBM][KS];
+    {
+      float mean[TBM], rstd[TBM];
+#pragma unroll
+      for (int tb = 0; tb < TBM; ++tb) {
+        float sm = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) sm += (oacc[ob][tb][0] + oacc[ob][tb][1]) + (oacc[ob][tb][2] + oacc[ob][tb][3]);
+        mean[tb] = hrow_sum4(sm) * (1.0f / DD);
+        float sq = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+          const f32x4 dl = oacc[ob][tb] - mean[tb];
+          sq += (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]);
+        }
+        rstd[tb] = __builtin_amdgcn_rsqf(hrow_sum4(sq) * (1.0f / DD) + eps);
+      }
+      f32x4 nrm[2 * KS][TBM];
+#pragma unroll
+      for (int ob = 0; ob < 2 * KS; ++ob) {
+        if (ob < OB) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(g2s + ob * 16 + fg * 4), b = *reinterpret_cast<const f32x4*>(e2s + ob * 16 + fg * 4);
+#pragma unroll
+          for (int tb = 0; tb < TBM; ++tb) nrm[ob][tb] = (oacc[ob][tb] - mean[tb]) * rstd[tb] * g + b;
+        } else {
+#pragma unroll
+          for (int tb = 0; tb < TBM; ++tb) nrm[ob][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int tb = 0; tb < TBM; ++tb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xn[tb][ks] = pack8(nrm[2 * ks][tb], nrm[2 * ks + 1][tb]);
+    }
+    // the fc2 accumulators start from x + b2
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b2s + ob * 16 + fg * 4);
+#pragma unroll
+      for (int tb = 0; tb < TBM; ++tb) oacc[ob][tb] += bv;
+    }
+    auto step = [&]() -> const char* {
+      const int left = ctotal - 1 - c;
+      wait_tiles<PTM>(left < LAM - 1 ? left : LAM - 1);
+      __builtin_amdgcn_s_barrier();
+      if (c + LAM < ctotal) issue(c + LAM);
+      const char* m = smem + (c % NSTM) * MAT;
+      ++c;
+      return m;
+    };
+#pragma unroll 1
+    for (int ch = 0; ch < C::NCH; ++ch) {
+      const char* m1 = step();
+      // ---- H^T[64 hidden][tokens] = W1 step . LN(x)^T (+ b1), GELU, rounded: fc2's B operand in k-slot order
+      half8_t pf[TBM][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 acc[2][TBM];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + ch * 64 + (2 * s + r2) * 16 + fg * 4);
+#pragma unroll
+          for (int tb = 0; tb < TBM; ++tb) acc[r2][tb] = bv;
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const half8_t a = *reinterpret_cast<const half8_t*>(m1 + ((2 * s + r2) * 16 + fr) * C::ROW1 + ((((ks << 2) + fg) ^ fr) << 4));
+#pragma unroll
+            for (int tb = 0; tb < TBM; ++tb) acc[r2][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xn[tb][ks], acc[r2][tb], 0, 0, 0);
+          }
+#pragma unroll
+        for (int tb = 0; tb < TBM; ++tb) {
+          const f32x2 g0 = gelu_pk(f32x2{acc[0][tb][0], acc[0][tb][1]}), g1 = gelu_pk(f32x2{acc[0][tb][2], acc[0][tb][3]});
+          const f32x2 g2 = gelu_pk(f32x2{acc[1][tb][0], acc[1][tb][1]}), g3 = gelu_pk(f32x2{acc[1][tb][2], acc[1][tb][3]});
+          pf[tb][s] = half8_t{(half_t)g0[0], (half_t)g0[1], (half_t)g1[0], (half_t)g1[1], (half_t)g2[0], (half_t)g2[1], (half_t)g3[0], (half_t)g3[1]};
+        }
+      }
+      // ---- x^T[o][token] += W2[:, step] . H   (image rows of 128 B: chunk c of row r at c ^ ((r >> 1) & 7))
+      const char* m2 = C::ONE ? m1 + 16384 : step();
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const half8_t a = *reinterpret_cast<const half8_t*>(m2 + (ob * 16 + fr) * 128 + ((((s << 2) + fg) ^ ((fr >> 1) & 7)) << 4));
+#pragma unroll
+          for (int tb = 0; tb < TBM; ++tb) oacc[ob][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[tb][s], oacc[ob][tb], 0, 0, 0);
+        }
+    }
+    // ---- outputs: x; its f16 copy; the next block's layer_norm1 rows
+#pragma unroll
+    for (int tb = 0; tb < TBM; ++tb) {
+      if (live[tb]) {
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) *reinterpret_cast<f32x4*>(x + trow[tb] * ldx + ob * 16 + fg * 4) = oacc[ob][tb];
+        if (x16) {
+#pragma unroll
+          for (int ob = 0; ob < OB; ++ob) {
+            const f32x4 v = oacc[ob][tb];
+            *reinterpret_cast<half4_t*>(x16 + trow[tb] * DD + ob * 16 + fg * 4) = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          }
+        }
+      }
+      if (h_n) {
+        float sm = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) sm += (oacc[ob][tb][0] + oacc[ob][tb][1]) + (oacc[ob][tb][2] + oacc[ob][tb][3]);
+        const float mean = hrow_sum4(sm) * (1.0f / DD);
+        float sq = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+          const f32x4 a = oacc[ob][tb] - mean;
+          sq += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+        }
+        const float rstd = __builtin_amdgcn_rsqf(hrow_sum4(sq) * (1.0f / DD) + eps);
+        if (live[tb]) {
+#pragma unroll
+          for (int ob = 0; ob < OB; ++ob) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gns + ob * 16 + fg * 4), b = *reinterpret_cast<const f32x4*>(ens + ob * 16 + fg * 4);
+            const f32x4 v = (oacc[ob][tb] - mean) * rstd * g + b;
+            *reinterpret_cast<half4_t*>(h_n + trow[tb] * DD + ob * 16 + fg * 4) = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int DD>
+int launch_hiera_mlp(float* x, int64_t ldx, const void* img, const float* bias, float eps, int64_t rows, void* x16, void* h_next, hipStream_t st) {
+  constexpr int SM = NSTM * MAT + MlpCfg<DD>::NB * 4, TBM = mlp_tb<DD>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    LMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hiera_mlp_kernel<DD>), hipFuncAttributeMaxDynamicSharedMemorySize, SM));
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    LMX_HIP(hipGetDevice(&dev));
+    LMX_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int64_t ngroup = (rows + NWM * TBM * 16 - 1) / (NWM * TBM * 16);
+  LMX_REQUIRE(ngroup < (1ll << 31), "lmx_k_ln_mlp_img: too many rows");
+  const unsigned grid = (unsigned)(ngroup < n_cu ? ngroup : n_cu);
+  hipLaunchKernelGGL(hiera_mlp_kernel<DD>, dim3(grid), dim3(NWM * 64), SM, st, x, ldx, reinterpret_cast<const half_t*>(img), bias, eps, rows,
+                     reinterpret_cast<half_t*>(x16), reinterpret_cast<half_t*>(h_next), (int)ngroup);
+  return lmx_launch_check("hiera_mlp_kernel");
+}
+
+}  // namespace
+
+// x f32 [rows, ldx] updated in place: x += fc2(gelu(fc1(LayerNorm(x)))), D = 112 or 224.  w_img f16 [NIMG][16384], bias f32
+// [b1 (4D) | b2 | gamma2 | beta2 | gamma_next | beta_next (D each)]: lmx/sam.py pack_ln_mlp.  x16 / h_next as in lmx_k_ln_mlp.
+extern "C" int lmx_k_ln_mlp_img(float* x, int64_t ldx, const void* w_img, const float* bias, int64_t rows, int D_, float eps, void* x16,
+                                void* h_next, lmx_stream_t stream) {
+  LMX_REQUIRE(x && w_img && bias, "lmx_k_ln_mlp_img: null pointer");
+  LMX_REQUIRE(D_ == 112 || D_ == 224, "lmx_k_ln_mlp_img: D=%d (built for 112 and 224)", D_);
+  LMX_REQUIRE(rows > 0 && ldx >= D_ && ldx % 4 == 0 && aligned16(x) && aligned16(w_img), "lmx_k_ln_mlp_img: rows / ldx / alignment");
+  LMX_REQUIRE((((uintptr_t)x16) & 7) == 0 && (((uintptr_t)h_next) & 7) == 0, "lmx_k_ln_mlp_img: x16 / h_next must be 8-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (D_ == 112) return launch_hiera_mlp<112>(x, ldx, w_img, bias, eps, rows, x16, h_next, st);
+  return launch_hiera_mlp<224>(x, ldx, w_img, bias, eps, rows, x16, h_next, st);
+}

@@ -52,6 +52,7 @@ SIGNATURES = {
     "lmx_k_hiera_attn8": (_I, [_VP, _VP, _I64, _VP, _VP, _F, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _F, _VP]),
     "lmx_k_hiera_attn4": (_I, [_VP, _VP, _I64, _VP, _VP, _I, _I, _I, _I, _I, _F, _VP]),
     "lmx_k_hiera_attn_pool": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _F, _VP]),
+    "lmx_k_ln_mlp_img": (_I, [_VP, _I64, _VP, _VP, _I64, _I, _F, _VP, _VP, _VP]),
     "lmx_k_layernorm": (_I, [_VP, _I, _I64, _VP, _VP, _VP, _I, _I64, _I, _I, _F, _I, _VP]),
     "lmx_k_attention": (_I, [C.POINTER(AttnDesc), _VP]),
     "lmx_k_relpos_tables": (_I, [C.POINTER(AttnDesc), _VP, _VP, _I, _VP, _VP]),

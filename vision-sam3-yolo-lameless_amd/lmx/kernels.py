@@ -353,6 +353,34 @@ def hiera_attn_pool(h, packed, n_img, Gh, Gw, heads, Dout):
     return out
 
 
+def ln_mlp_img_ok(D, rows):
+    """Where lmx_k_ln_mlp_img (the streamed-image form of the fused LN + MLP, csrc/hiera.hip) replaces csrc/mlp.hip's kernel: D = 112 /
+    224 from the row counts at which its 256 persistent workgroups are busy for many passes (measured cross-over, tools/mlp_probe.py).
+    LMX_MLP_IMG=0: never; =2: at every row count."""
+    mode = os.environ.get("LMX_MLP_IMG", "1")
+    if mode == "0" or D not in (112, 224):
+        return False
+    return mode == "2" or rows >= (1_300_000 if D == 112 else 330_000)
+
+
+def ln_mlp_img(x, packed, eps, x16=None, h_next=None):
+    """x (f32 [rows, D], in place) += fc2(gelu(fc1(LayerNorm(x)))) with the weights as LDS images (lmx.sam.pack_ln_mlp: (w_img, bias);
+    bias carries layer_norm2's and — when h_next is given — the next block's layer_norm1's vectors).  x16 / h_next: as ln_mlp."""
+    img, bias = packed
+    dev = _dev(x, img, bias, x16, h_next)
+    rows, D, ldx = _rows(x, "ln_mlp_img x")
+    nimg = 7 if D == 112 else 28
+    if x.dtype != torch.float32 or tuple(img.shape) != (nimg, 16384) or img.dtype != torch.float16 or not img.is_contiguous() \
+            or bias.numel() != 9 * D or bias.dtype != torch.float32:
+        raise LmxError("ln_mlp_img: x must be f32 [rows, D] and the packed operands those of lmx.sam.pack_ln_mlp")
+    for t, name in ((x16, "x16"), (h_next, "h_next")):
+        if t is not None and (t.dtype != torch.float16 or tuple(t.shape) != (rows, D) or not t.is_contiguous()):
+            raise LmxError(f"ln_mlp_img: {name} must be contiguous float16 [rows, D]")
+    check(_lib.load().lmx_k_ln_mlp_img(_ptr(x), ldx, _ptr(img), _ptr(bias), rows, D, float(eps), _ptr(x16), _ptr(h_next), _stream(dev)),
+          "lmx_k_ln_mlp_img")
+    return x
+
+
 def _attn_desc(q, k, v, out, B, H, Tq, Tk, hd, scale, window, pad_k, pad_v):
     d = AttnDesc()
     d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
@@ -733,6 +761,9 @@ def _work(name, args):
     if name == "lmx_k_layernorm":
         in_dt, out_dt, rows, D = args[1], args[6], args[8], args[9]
         return "layernorm", 0.0, rows * D * ((4 if in_dt == F32 else 2) + (4 if out_dt == F32 else 2)), f"layernorm rows={rows} D={D} in={in_dt} out={out_dt}"
+    if name == "lmx_k_ln_mlp_img":
+        rows, D = args[4], args[5]
+        return "fused ln+mlp", 16.0 * D * D * rows, (8 + (2 if args[7] else 0) + (2 if args[8] else 0)) * D * rows, f"ln_mlp_img rows={rows} D={D}"
     if name == "lmx_k_ln_mlp":
         rows, D = args[8], args[9]
         return "fused ln+mlp", 16.0 * D * D * rows, (16 + (2 if args[12] else 0) + (2 if args[15] else 0)) * D * rows, f"ln_mlp rows={rows} D={D}"

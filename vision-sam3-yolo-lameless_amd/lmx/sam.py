@@ -245,6 +245,36 @@ def pack_hiera_attn_pool(wsc, bsc, wqkv, bqkv, wo, bo, heads):
     return np.stack(imgs), bias
 
 
+def pack_ln_mlp(w1, b1, w2, b2, g2, e2, gn=None, en=None):
+    """Operands of lmx_k_ln_mlp_img (csrc/hiera.hip): w1 [4D, D], b1 [4D], w2 [D, 4D], b2 [D] (torch Linear layouts), layer_norm2's
+    g2 / e2 and — for the kernel's h_next output — the next block's layer_norm1's gn / en (numpy, f32; D = 112 or 224).  Per step of
+    64 hidden units: the 64 rows of w1 with their D input columns in MFMA k-slot order (rows of 256 bytes at D = 112, 512 at 224;
+    16-byte chunk c of row r at c ^ (r & 15)) and the D rows x 64 columns of w2, columns in k-slot order (rows of 128 bytes, chunk c of
+    row r at c ^ ((r >> 1) & 7)); at D = 112 both halves share an image (w2's at byte 16384), at D = 224 they alternate."""
+    D = w2.shape[0]
+    cols = 128 if D <= 128 else 256
+    nks = cols // 32
+    kslot = np.array([16 * (2 * s_ + hb) + 4 * g + i for s_ in range(nks) for g in range(4) for hb in range(2) for i in range(4)])  # feature at position
+    k15, k7 = (lambda r: r & 15), (lambda r: (r >> 1) & 7)
+    imgs = []
+    for ch in range(4 * D // 64):
+        m1 = np.zeros((64, cols), np.float16)
+        ok = kslot < D
+        m1[:, ok] = w1[64 * ch: 64 * ch + 64][:, kslot[ok]].astype(np.float16)
+        m2 = np.zeros((D, 64), np.float16)
+        m2[:, :] = w2[:, 64 * ch + kslot[:64]].astype(np.float16)
+        i1, i2 = _lds_image(m1, k15), _lds_image(m2, k7)
+        if D <= 128:
+            both = i1.copy()
+            both[8192:8192 + D * 64] = i2[:D * 64]
+            imgs.append(both)
+        else:
+            imgs += [i1, i2]
+    z = np.zeros((D,), np.float32)
+    bias = np.concatenate([b1, b2, g2, e2, gn if gn is not None else z, en if en is not None else z]).astype(np.float32)
+    return np.stack(imgs), bias
+
+
 class HieraEncoder:
     """Device-resident Hiera trunk + FPN.  ``encode(frames)`` -> dict(fpn=[3 NHWC f16 levels, high->low res],
     stages=[4 f32 stage outputs]).  Token grids are [n, H, W, C] row-major throughout (no partition copies)."""
@@ -307,6 +337,15 @@ class HieraEncoder:
                     np.asarray(sd[p + "attn.qkv.weight"], np.float32), np.asarray(qkv_b, np.float32),
                     np.asarray(sd[p + "attn.proj.weight"], np.float32), np.asarray(sd[p + "attn.proj.bias"], np.float32), heads))
             self.blocks.append(blk)
+        for i, blk in enumerate(self.blocks):  # the fused MLP's operands as LDS images, with the NEXT block's layer_norm1 vectors
+            if blk["dim_out"] in (112, 224) and self.fused_mlp:
+                p = f"backbone.blocks.{i}."
+                nx = f"backbone.blocks.{i + 1}." if i + 1 < len(self.blocks) else None
+                f32 = lambda k: np.asarray(sd[k], np.float32)  # noqa: E731
+                blk["mlp_img"] = tuple(torch.from_numpy(a).to(dev) for a in pack_ln_mlp(
+                    f32(p + "mlp.proj_in.weight"), f32(p + "mlp.proj_in.bias"), f32(p + "mlp.proj_out.weight"), f32(p + "mlp.proj_out.bias"),
+                    f32(p + "layer_norm2.weight"), f32(p + "layer_norm2.bias"),
+                    f32(nx + "layer_norm1.weight") if nx else None, f32(nx + "layer_norm1.bias") if nx else None))
         n = len(cfg.dims) - 1
         self.neck = [(t16(sd[f"neck.convs.{n - i}.weight"][:, :, 0, 0]), t32(sd[f"neck.convs.{n - i}.bias"])) for i in range(n + 1)]
         self.lut = t32(sam_norm_lut())
@@ -384,7 +423,10 @@ class HieraEncoder:
                 if i + 1 < len(self.blocks) and not (self._attn8(i + 1, H, W) and self.blocks[i + 1]["attn8_ln"]):  # the next block's layer_norm1, on the rows while the kernel still holds them
                     h_next = torch.empty((n * H * W, D), dtype=torch.float16, device=dev)
                     nxt = (self.blocks[i + 1]["g1"], self.blocks[i + 1]["b1"], h_next)
-                K.ln_mlp(x, B["g2"], B["b2"], B["w1"], B["bb1"], B["w2"], B["bb2"], cfg.eps, x16=x16, next_ln=nxt)  # one pass over x (csrc/mlp.hip)
+                if "mlp_img" in B and K.ln_mlp_img_ok(D, n * H * W):  # the streamed-image form (csrc/hiera.hip): the next block's LayerNorm vectors are packed in
+                    K.ln_mlp_img(x, B["mlp_img"], cfg.eps, x16=x16, h_next=h_next)
+                else:
+                    K.ln_mlp(x, B["g2"], B["b2"], B["w1"], B["bb1"], B["w2"], B["bb2"], cfg.eps, x16=x16, next_ln=nxt)  # one pass over x (csrc/mlp.hip)
             else:
                 h2 = K.layernorm(x, B["g2"], B["b2"], cfg.eps)
                 u = K.gemm(h2, B["w1"], bias=B["bb1"], act=K.ACT_GELU)
