@@ -1100,22 +1100,25 @@ __global__ __launch_bounds__(NWM * 64, 2) void hiera_mlp_kernel(float* __restric
         }
         rstd[tb] = __builtin_amdgcn_rsqf(hrow_sum4(sq) * (1.0f / DD) + eps);
       }
-      f32x4 nrm[2 * KS][TBM];
+      // two feature blocks (one k-step of fc1) at a time: the normalised values are short-lived
 #pragma unroll
-      for (int ob = 0; ob < 2 * KS; ++ob) {
-        if (ob < OB) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(g2s + ob * 16 + fg * 4), b = *reinterpret_cast<const f32x4*>(e2s + ob * 16 + fg * 4);
+      for (int ks = 0; ks < KS; ++ks) {
+        f32x4 nrm[2][TBM];
 #pragma unroll
-          for (int tb = 0; tb < TBM; ++tb) nrm[ob][tb] = (oacc[ob][tb] - mean[tb]) * rstd[tb] * g + b;
-        } else {
+        for (int hb = 0; hb < 2; ++hb) {
+          const int ob = 2 * ks + hb;
+          if (ob < OB) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(g2s + ob * 16 + fg * 4), b = *reinterpret_cast<const f32x4*>(e2s + ob * 16 + fg * 4);
 #pragma unroll
-          for (int tb = 0; tb < TBM; ++tb) nrm[ob][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tb = 0; tb < TBM; ++tb) nrm[hb][tb] = (oacc[ob < OB ? ob : 0][tb] - mean[tb]) * rstd[tb] * g + b;
+          } else {
+#pragma unroll
+            for (int tb = 0; tb < TBM; ++tb) nrm[hb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
+#pragma unroll
+        for (int tb = 0; tb < TBM; ++tb) xn[tb][ks] = pack8(nrm[0][tb], nrm[1][tb]);
       }
-#pragma unroll
-      for (int tb = 0; tb < TBM; ++tb)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xn[tb][ks] = pack8(nrm[2 * ks][tb], nrm[2 * ks + 1][tb]);
     }
     // the fc2 accumulators start from x + b2
 #pragma unroll
