@@ -1009,7 +1009,8 @@ extern "C" int lmx_k_hiera_attn_pool(const void* h, float* out, const void* w_im
 // is 56 - 90 MFMAs per wave.  It pays from a few hundred thousand rows: 1123 -> 966 us at 1.97 M rows of D = 112, 825 -> 736 us at
 // 491 520 rows of D = 224 (tools/mlp_probe.py, with the next block's LayerNorm output), but 346 -> 401 and 236 -> 314 us at a third
 // of those rows — 256 persistent workgroups with 3 - 7 passes each start and drain badly — so lmx/sam.py keeps csrc/mlp.hip's kernel
-// for the small batches of the reference schedule.  A wave reads its 32 f32 rows once in accumulator layout (lane (token fr, fg) holds features 16 ob + 4 fg .. + 3):
+// for the small batches of the reference schedule.  (Tried on top, no change: fc2 of step c - 1 issued under the GELU of step c
+// inside the wave — 959 / 731 us against 952 - 966 / 736 - 750: the kernel is not waiting for its matrix and vector work to overlap.)  A wave reads its 32 f32 rows once in accumulator layout (lane (token fr, fg) holds features 16 ob + 4 fg .. + 3):
 // they are layer_norm2's input (statistics over the four lanes of a token), and + b2 the initial fc2 accumulators; the normalised
 // rows, rounded to f16, are fc1's B operand in k-slot order (W1's columns are stored in that order), fc1's GELU'd accumulators are
 // fc2's B operand (W2's columns of a step likewise).  Outputs as lmx_k_ln_mlp: x in place, optionally its f16 copy and the next
