@@ -324,3 +324,22 @@ def test_hiera_fused_attention_halves_match_unfused_launches(cuda, monkeypatch):
             rel, cos = _rel(a.float().cpu(), b.float().cpu())
             print(f"fused vs unfused {name}[{lvl}]: rel {rel:.2e} cos-1 {cos - 1:.1e}")
             assert rel < 2e-3 and cos > 1 - 1e-5, (name, lvl, rel, cos)
+
+
+def test_hiera_encoder_result_does_not_depend_on_the_batch(cuda):
+    """A frame's Hiera-B+ output is bit-identical alone, in a batch of 3 and as the last frame of a batch of 7 (DESIGN.md section 3,
+    Reproducibility): no launch of the encoder — the fused kernels of csrc/hiera.hip included — may pick a code path with a different
+    summation order from the batch size.  This is what keeps a sharded clip's JSON equal to the unsharded one."""
+    from lmx import sam, synth, weights
+
+    cfg = sam.hiera_b_plus()
+    enc = sam.HieraEncoder(cfg, weights.synth_state_dict(sam.param_spec(cfg), 5), cuda)
+    frames = torch.from_numpy(np.stack([synth.synth_frame(3, 40 + i) for i in range(7)], 0)).to(cuda)
+    alone = enc.encode(frames[6:7])
+    in3 = enc.encode(frames[4:7])
+    in7 = enc.encode(frames)
+    torch.cuda.synchronize()
+    for name in ("fpn", "stages"):
+        for lvl in range(len(alone[name])):
+            a = alone[name][lvl][0]
+            assert torch.equal(a, in3[name][lvl][2]) and torch.equal(a, in7[name][lvl][6]), f"{name}[{lvl}] depends on the batch"

@@ -1008,8 +1008,8 @@ extern "C" int lmx_k_hiera_attn_pool(const void* h, float* out, const void* w_im
 // time is that fixed cost).  Here a workgroup is 8 waves x 32 (D = 224) or 48 (D = 112) tokens per pass over the weights and a step
 // is 56 - 90 MFMAs per wave.  It pays from a few hundred thousand rows: 1123 -> 966 us at 1.97 M rows of D = 112, 825 -> 736 us at
 // 491 520 rows of D = 224 (tools/mlp_probe.py, with the next block's LayerNorm output), but 346 -> 401 and 236 -> 314 us at a third
-// of those rows — 256 persistent workgroups with 3 - 7 passes each start and drain badly — so lmx/sam.py keeps csrc/mlp.hip's kernel
-// for the small batches of the reference schedule.  (Tried on top, no change: fc2 of step c - 1 issued under the GELU of step c
+// of those rows — 256 persistent workgroups with 3 - 7 passes each start and drain badly.  lmx/sam.py uses it at every batch size all
+// the same: the two kernels sum in different orders, and a frame's result must not depend on the batch it rides in.  (Tried on top, no change: fc2 of step c - 1 issued under the GELU of step c
 // inside the wave — 959 / 731 us against 952 - 966 / 736 - 750: the kernel is not waiting for its matrix and vector work to overlap.)  A wave reads its 32 f32 rows once in accumulator layout (lane (token fr, fg) holds features 16 ob + 4 fg .. + 3):
 // they are layer_norm2's input (statistics over the four lanes of a token), and + b2 the initial fc2 accumulators; the normalised
 // rows, rounded to f16, are fc1's B operand in k-slot order (W1's columns are stored in that order), fc1's GELU'd accumulators are

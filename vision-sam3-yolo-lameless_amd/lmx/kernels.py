@@ -355,12 +355,11 @@ def hiera_attn_pool(h, packed, n_img, Gh, Gw, heads, Dout):
 
 def ln_mlp_img_ok(D, rows):
     """Where lmx_k_ln_mlp_img (the streamed-image form of the fused LN + MLP, csrc/hiera.hip) replaces csrc/mlp.hip's kernel: D = 112 /
-    224 from the row counts at which its 256 persistent workgroups are busy for many passes (measured cross-over, tools/mlp_probe.py).
-    LMX_MLP_IMG=0: never; =2: at every row count."""
-    mode = os.environ.get("LMX_MLP_IMG", "1")
-    if mode == "0" or D not in (112, 224):
-        return False
-    return mode == "2" or rows >= (1_300_000 if D == 112 else 330_000)
+    224 at EVERY row count.  It is faster only from ~1.3 M / 0.33 M rows (tools/mlp_probe.py) and 10 - 30 % slower below a third of
+    that, but the two kernels sum in different orders, and a frame's result must not depend on the batch it rides in (DESIGN.md section
+    3, Reproducibility: the multi-GPU JSON equals the single-GPU one whatever the sharding) — so one kernel serves all batch sizes.
+    LMX_MLP_IMG=0: csrc/mlp.hip's kernel everywhere."""
+    return D in (112, 224) and os.environ.get("LMX_MLP_IMG", "1") != "0"
 
 
 def ln_mlp_img(x, packed, eps, x16=None, h_next=None):
