@@ -187,3 +187,26 @@ def test_fused_step_is_bit_reproducible(cuda, n_frames):
         for k in ref:
             assert torch.equal(got[k], ref[k]), f"{k} differs between runs (serial={serial})"
     fx.serial = False
+
+
+@pytest.mark.parametrize("precision", [None, "f16"])
+def test_fused_step_on_shards_equals_the_whole_clip(cuda, precision):
+    """What makes the multi-GPU JSON equal to the single-GPU one: FusedExtractor.step on contiguous blocks of a
+    clip — the ranks' shards, ragged here: 13 + 11 of 24 frames — returns, frame for frame, the bits of the step on the whole clip,
+    on the exact plans the services run and on the throughput plans; every kernel choice is independent of the batch size."""
+    import numpy as np
+    import torch
+
+    from lmx import pipeline, synth
+
+    fx = pipeline.FusedExtractor(cuda)
+    frames = torch.from_numpy(np.stack([synth.synth_frame(3, 40 + i) for i in range(24)], 0)).to(cuda)
+    whole = {k: v.clone() for k, v in fx.step(frames, keep_byte_masks=True, precision=precision).items()}
+    parts = [{k: v.clone() for k, v in fx.step(frames[a:b], keep_byte_masks=True, precision=precision).items()} for a, b in ((0, 13), (13, 24))]
+    torch.cuda.synchronize()
+    for k, v in whole.items():
+        if v.dim() == 0 or v.shape[0] != 24:
+            continue
+        got = torch.cat([p[k] for p in parts], 0)
+        assert torch.equal(got, v), f"{k}: the shards' rows differ from the whole clip's"
+    assert any(v.dim() > 0 and v.shape[0] == 24 for v in whole.values())
